@@ -1,0 +1,110 @@
+"""Synthetic setups (host side): deterministic initial fields for the benchmark and parity configurations.
+
+Every function fills the global fields of an LBM-like object exposing N=(Nx,Ny,Nz) and numpy arrays
+rho[z,y,x], u[3,z,y,x], flags[z,y,x] (and F[3,z,y,x] with FORCE_FIELD).  The formulae follow the setups
+the reference ships in FluidX3D-master/src/setup.cpp.bak.
+"""
+import numpy as np
+
+TYPE_S, TYPE_E, TYPE_X, TYPE_Y = 0x01, 0x02, 0x40, 0x80
+
+
+def _grid(lbm):
+    Nx, Ny, Nz = lbm.N
+    z, y, x = np.meshgrid(np.arange(Nz), np.arange(Ny), np.arange(Nx), indexing="ij")
+    return x, y, z
+
+
+def nu_from_Re(Re, x, u):
+    """FluidX3D-master/src/units.hpp nu_from_Re: nu = x*u/Re, evaluated in float."""
+    return float(np.float32(np.float32(x) * np.float32(u)) / np.float32(Re))
+
+
+def taylor_green(lbm, A=0.25, periodicity=1):
+    """3D Taylor-Green vortices, fully periodic (setup.cpp.bak:40-59)."""
+    Nx, Ny, Nz = lbm.N
+    x, y, z = _grid(lbm)
+    f32 = np.float32
+    a, b, c = f32(Nx) / f32(periodicity), f32(Ny) / f32(periodicity), f32(Nz) / f32(periodicity)
+    fx = x.astype(f32) + f32(0.5) - f32(0.5) * f32(Nx)
+    fy = y.astype(f32) + f32(0.5) - f32(0.5) * f32(Ny)
+    fz = z.astype(f32) + f32(0.5) - f32(0.5) * f32(Nz)
+    pif = f32(3.1415927)
+    A = f32(A)
+    ax, ay, az = f32(2.0) * pif * fx / a, f32(2.0) * pif * fy / b, f32(2.0) * pif * fz / c
+    lbm.u[0] = A * np.cos(ax) * np.sin(ay) * np.sin(az)
+    lbm.u[1] = -A * np.sin(ax) * np.cos(ay) * np.sin(az)
+    lbm.u[2] = A * np.sin(ax) * np.sin(ay) * np.cos(az)
+    lbm.rho[...] = f32(1.0) - A * A * f32(3.0) / f32(4.0) * (np.cos(f32(4.0) * pif * fx / a) + np.cos(f32(4.0) * pif * fy / b))
+    lbm.flags[...] = 0
+
+
+def lid_cavity(lbm, u_lid=0.1):
+    """Lid-driven cavity: all six faces solid, the lid z=Nz-1 moves in +y (setup.cpp.bak:236-249).
+    Needs MOVING_BOUNDARIES."""
+    Nx, Ny, Nz = lbm.N
+    x, y, z = _grid(lbm)
+    lbm.rho[...] = 1.0
+    lbm.u[...] = 0.0
+    lbm.u[1][z == Nz - 1] = np.float32(u_lid)
+    wall = (x == 0) | (x == Nx - 1) | (y == 0) | (y == Ny - 1) | (z == 0) | (z == Nz - 1)
+    lbm.flags[...] = np.where(wall, TYPE_S, 0).astype(np.uint8)
+
+
+def obstacle_mask(Nx, Ny, seed=42, n_pillars=12):
+    """Seeded 2-D obstacle mask (pillars of random radius) used for the extruded channel geometry."""
+    rng = np.random.RandomState(seed)
+    yy, xx = np.meshgrid(np.arange(Ny), np.arange(Nx), indexing="ij")
+    mask = np.zeros((Ny, Nx), dtype=bool)
+    for _ in range(n_pillars):
+        cx, cy = rng.uniform(0.1, 0.9) * Nx, rng.uniform(0.2, 0.8) * Ny
+        r = rng.uniform(0.02, 0.06) * min(Nx, Ny)
+        mask |= (xx - cx) ** 2 + (yy - cy) ** 2 <= r * r
+    return mask
+
+
+def channel(lbm, seed=42, u0=0.0):
+    """Force-driven channel, periodic in x, solid walls in y and z, plus an obstacle mask extruded along z.
+    Needs VOLUME_FORCE (the force comes from the LBM constructor)."""
+    Nx, Ny, Nz = lbm.N
+    x, y, z = _grid(lbm)
+    lbm.rho[...] = 1.0
+    lbm.u[...] = 0.0
+    lbm.u[0][...] = np.float32(u0)
+    wall = (y == 0) | (y == Ny - 1) | (z == 0) | (z == Nz - 1)
+    wall |= obstacle_mask(Nx, Ny, seed)[None, :, :]
+    lbm.flags[...] = np.where(wall, TYPE_S, 0).astype(np.uint8)
+
+
+def inflow_box(lbm, u_in=0.075, radius_frac=0.15):
+    """What the GUI's generated setup does (main.py:145-198): u.x preset everywhere outside solids, all six
+    faces TYPE_E, a solid body in the middle (a sphere stands in for the voxelized STL).
+    Needs EQUILIBRIUM_BOUNDARIES."""
+    Nx, Ny, Nz = lbm.N
+    x, y, z = _grid(lbm)
+    r2 = (x - 0.5 * Nx + 0.5) ** 2 + (y - 0.5 * Ny + 0.5) ** 2 + (z - 0.5 * Nz + 0.5) ** 2
+    solid = r2 <= (radius_frac * min(Nx, Ny, Nz)) ** 2
+    lbm.rho[...] = 1.0
+    lbm.u[...] = 0.0
+    lbm.u[0][~solid] = np.float32(u_in)
+    flags = np.where(solid, TYPE_S, 0).astype(np.uint8)
+    face = (x == 0) | (x == Nx - 1) | (y == 0) | (y == Ny - 1) | (z == 0) | (z == Nz - 1)
+    flags[face] = TYPE_E
+    lbm.flags[...] = flags
+
+
+def sphere_force(lbm, u_in=0.05, radius_frac=0.2):
+    """Sphere flagged TYPE_S|TYPE_X in a box with TYPE_E faces (Stokes-drag style, setup.cpp.bak:148-187).
+    Needs EQUILIBRIUM_BOUNDARIES; FORCE_FIELD gives the boundary force on the sphere."""
+    Nx, Ny, Nz = lbm.N
+    x, y, z = _grid(lbm)
+    r2 = (x - 0.5 * Nx + 0.5) ** 2 + (y - 0.5 * Ny + 0.5) ** 2 + (z - 0.5 * Nz + 0.5) ** 2
+    solid = r2 <= (radius_frac * min(Nx, Ny, Nz)) ** 2
+    lbm.rho[...] = 1.0
+    lbm.u[...] = 0.0
+    lbm.u[0][~solid] = np.float32(-u_in)
+    flags = np.zeros((Nz, Ny, Nx), dtype=np.uint8)
+    face = (x == 0) | (x == Nx - 1) | (y == 0) | (y == Ny - 1) | (z == 0) | (z == Nz - 1)
+    flags[face] = TYPE_E
+    flags[solid] = TYPE_S | TYPE_X
+    lbm.flags[...] = flags
