@@ -1,0 +1,41 @@
+// lbm_dispatch.hpp - run-time selection of a compiled stream_collide / update_fields instance.
+// Each (velocity set, storage) pair lives in its own translation unit so that the build parallelises.
+#pragma once
+#include "lbm_kernels.hpp"
+
+namespace lbm {
+
+typedef hipError_t (*collide_launch_fn)(const Args&, dim3 grid, dim3 block, hipStream_t stream);
+
+template <int Q, int ST, int COLL, int FEAT, int V, bool FO>
+hipError_t launch_collide(const Args& a, dim3 grid, dim3 block, hipStream_t stream) {
+	hipLaunchKernelGGL((k_collide<Q, ST, COLL, FEAT, V, FO>), grid, block, 0, stream, a);
+	return hipGetLastError();
+}
+
+// FEAT < 0 selects the instance that reads the feature mask at run time; FO = update_fields (always run-time features, V=1)
+template <int Q, int ST, int COLL, int FEAT> collide_launch_fn pick_v(int V) {
+	switch (V) {
+		case 4: return launch_collide<Q, ST, COLL, FEAT, 4, false>;
+		case 2: return launch_collide<Q, ST, COLL, FEAT, 2, false>;
+		default: return launch_collide<Q, ST, COLL, FEAT, 1, false>;
+	}
+}
+
+// per translation unit: returns nullptr when (COLL, FEAT) has no compiled instance
+collide_launch_fn select_collide_q19_fp32(int COLL, int FEAT, int V, bool FO);
+collide_launch_fn select_collide_q19_fp16s(int COLL, int FEAT, int V, bool FO);
+collide_launch_fn select_collide_q19_fp16c(int COLL, int FEAT, int V, bool FO);
+collide_launch_fn select_collide_q27_fp32(int COLL, int FEAT, int V, bool FO);
+collide_launch_fn select_collide_q27_fp16s(int COLL, int FEAT, int V, bool FO);
+collide_launch_fn select_collide_q27_fp16c(int COLL, int FEAT, int V, bool FO);
+collide_launch_fn select_collide_small(int Q, int ST, int COLL, int FEAT, int V, bool FO); // D2Q9, D3Q15
+
+// LBM_SELECT_BODY(Q, ST, specialised feature masks...) expands to the body of one select_collide_* function
+#define LBM_SPECIALISE(Q, ST, MASK) \
+	if (FEAT == (MASK)) return COLL == COLL_TRT ? pick_v<Q, ST, COLL_TRT, (MASK)>(V) : pick_v<Q, ST, COLL_SRT, (MASK)>(V);
+#define LBM_GENERIC(Q, ST) \
+	if (FO) return COLL == COLL_TRT ? launch_collide<Q, ST, COLL_TRT, -1, 1, true> : launch_collide<Q, ST, COLL_SRT, -1, 1, true>; \
+	if (FEAT < 0) return COLL == COLL_TRT ? pick_v<Q, ST, COLL_TRT, -1>(V) : pick_v<Q, ST, COLL_SRT, -1>(V);
+
+} // namespace lbm

@@ -1,0 +1,522 @@
+// lbmhip.hip - implementation of the C ABI declared in include/lbmhip.h (domain handle, launches, copies,
+// halo staging).  Host code of a HIP translation unit; the heavy stream_collide instances live in collide_*.hip.
+#include "../../include/lbmhip.h"
+#define LBM_SMALL_KERNELS
+#include "lbm_dispatch.hpp"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace lbm;
+
+// ---------------------------------------------------------------------------------------------- errors
+static thread_local std::string g_error;
+static int fail(const char* fmt, ...) {
+	char buf[1024];
+	va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+	g_error = buf;
+	return 1;
+}
+#define HIP_TRY(expr) do { const hipError_t e_ = (expr); if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+#define NEED(cond, ...) do { if (!(cond)) return fail(__VA_ARGS__); } while (0)
+
+// ---------------------------------------------------------------------------------------------- domain
+struct lbmhip_domain {
+	lbmhip_config cfg;
+	uint64_t N;
+	uint32_t fpxx_bytes;
+	void* field[5];
+	uint64_t field_bytes[5];
+	hipStream_t own_stream, stream, comm_stream, saved_stream;
+	hipEvent_t ev_fork, ev_join;
+	void* halo_own[4];
+	void* halo[4];
+	uint64_t halo_capacity;
+	hipEvent_t ev_start, ev_stop, ev_packed, ev_copied;
+	int cells_per_thread, block;
+	float w;
+};
+
+static uint32_t q_transfers(uint32_t Q) { return Q == 9u ? 3u : Q == 27u ? 9u : 5u; }
+static uint32_t storage_bytes(uint32_t st) { return st == LBMHIP_FP32 ? 4u : 2u; }
+static bool valid_q(uint32_t Q) { return Q == 9u || Q == 15u || Q == 19u || Q == 27u; }
+
+struct DeviceGuard { // makes the domain's device current for the duration of a call
+	int prev; bool ok;
+	explicit DeviceGuard(int dev) : prev(0), ok(true) { if (hipGetDevice(&prev) != hipSuccess || (prev != dev && hipSetDevice(dev) != hipSuccess)) ok = false; }
+	~DeviceGuard() { int cur = 0; if (hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev); }
+};
+
+static Args make_args(const lbmhip_domain* d, uint64_t t, float fx, float fy, float fz) {
+	Args a;
+	a.fi = d->field[LBMHIP_FIELD_FI]; a.rho = (float*)d->field[LBMHIP_FIELD_RHO]; a.u = (float*)d->field[LBMHIP_FIELD_U];
+	a.flags = (uint8_t*)d->field[LBMHIP_FIELD_FLAGS]; a.F = (float*)d->field[LBMHIP_FIELD_F];
+	a.N = d->N; a.Nx = d->cfg.Nx; a.Ny = d->cfg.Ny; a.Nz = d->cfg.Nz;
+	a.hx = d->cfg.Dx > 1u; a.hy = d->cfg.Dy > 1u; a.hz = d->cfg.Dz > 1u;
+	a.z0 = a.hz; a.z1 = d->cfg.Nz-a.hz;
+	a.odd = (uint32_t)(t&1ull); a.features = d->cfg.features; a.xchunks = 1u;
+	a.fx = fx; a.fy = fy; a.fz = fz; a.w = d->w;
+	return a;
+}
+
+extern "C" {
+
+const char* lbmhip_last_error(void) { return g_error.c_str(); }
+const char* lbmhip_version(void) { return "lbmhip 0.1 (gfx950)"; }
+
+int lbmhip_device_count(int* count) {
+	NEED(count, "lbmhip_device_count: null argument");
+	int n = 0;
+	const hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess) { *count = 0; return fail("hipGetDeviceCount failed: %s", hipGetErrorString(e)); }
+	*count = n;
+	return 0;
+}
+int lbmhip_device_name(int device, char* name, uint64_t capacity) {
+	NEED(name && capacity > 0u, "lbmhip_device_name: null argument");
+	hipDeviceProp_t p;
+	HIP_TRY(hipGetDeviceProperties(&p, device));
+	snprintf(name, (size_t)capacity, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+	return 0;
+}
+int lbmhip_device_memory(int device, uint64_t* free_bytes, uint64_t* total_bytes) {
+	DeviceGuard g(device);
+	NEED(g.ok, "cannot select device %d", device);
+	size_t f = 0, t = 0;
+	HIP_TRY(hipMemGetInfo(&f, &t));
+	if (free_bytes) *free_bytes = f;
+	if (total_bytes) *total_bytes = t;
+	return 0;
+}
+
+// FluidX3D-master/src/lbm.cpp:37-50
+uint32_t lbmhip_bytes_per_cell_device(uint32_t Q, uint32_t storage, uint32_t features) {
+	uint32_t b = Q*storage_bytes(storage)+17u;
+	if (features&LBMHIP_FORCE_FIELD) b += 12u;
+	return b;
+}
+// FluidX3D-master/src/lbm.cpp:51-82
+uint32_t lbmhip_bandwidth_bytes_per_cell(uint32_t Q, uint32_t storage, uint32_t features) {
+	uint32_t b = Q*2u*storage_bytes(storage)+1u;
+	if (features&LBMHIP_UPDATE_FIELDS) b += 16u;
+	if (features&LBMHIP_FORCE_FIELD) b += 12u;
+	if (features&LBMHIP_MOVING_BOUNDARIES) b += Q-1u;
+	return b;
+}
+
+int lbmhip_domain_create(const lbmhip_config* c, lbmhip_domain** out) {
+	NEED(c && out, "lbmhip_domain_create: null argument");
+	*out = nullptr;
+	NEED((uint64_t)c->Nx*c->Ny*c->Nz > 0u, "Grid point number is 0: %ux%ux%u = 0.", c->Nx, c->Ny, c->Nz);
+	NEED(c->Dx*c->Dy*c->Dz > 0u, "You specified 0 LBM grid domains (%ux%ux%u).", c->Dx, c->Dy, c->Dz);
+	NEED(valid_q(c->velocity_set), "unsupported velocity set %u (use 9, 15, 19 or 27)", c->velocity_set);
+	NEED(c->velocity_set != 9u || c->Nz == 1u, "D2Q9 is the 2D velocity set. You have to set Nz=1u.");
+	NEED(c->storage <= LBMHIP_FP16C, "unknown DDF storage %u", c->storage);
+	NEED(c->collision <= LBMHIP_TRT, "No LBM collision operator selected (collision=%u).", c->collision);
+	NEED(c->nu > 0.0f, c->nu == 0.0f ? "Viscosity cannot be 0." : "Viscosity cannot be negative.");
+	NEED((c->features&~63u) == 0u, "unknown feature bits 0x%x", c->features);
+	for (int ax = 0; ax < 3; ax++) {
+		const uint32_t n = ax == 0 ? c->Nx : ax == 1 ? c->Ny : c->Nz, dd = ax == 0 ? c->Dx : ax == 1 ? c->Dy : c->Dz;
+		NEED(dd <= 1u || n >= 3u, "an axis with %u domains needs at least 1 cell between its two halo layers (size %u)", dd, n);
+	}
+	DeviceGuard g(c->device);
+	NEED(g.ok, "cannot select device %d", c->device);
+
+	lbmhip_domain* d = new lbmhip_domain();
+	memset(d, 0, sizeof(*d));
+	d->cfg = *c;
+	d->N = (uint64_t)c->Nx*c->Ny*c->Nz;
+	d->fpxx_bytes = storage_bytes(c->storage);
+	d->w = 1.0f/(3.0f*c->nu+0.5f); // relaxation rate, float like LBM_Domain::get_tau (lbm.hpp:132, lbm.cpp:509-511)
+	d->cells_per_thread = 0; // 0 = automatic
+	d->block = 0;
+	d->field_bytes[LBMHIP_FIELD_FI] = d->N*c->velocity_set*d->fpxx_bytes;
+	d->field_bytes[LBMHIP_FIELD_RHO] = d->N*4u;
+	d->field_bytes[LBMHIP_FIELD_U] = d->N*12u;
+	d->field_bytes[LBMHIP_FIELD_FLAGS] = d->N;
+	d->field_bytes[LBMHIP_FIELD_F] = (c->features&LBMHIP_FORCE_FIELD) ? d->N*12u : 0u;
+
+	auto cleanup = [&]() { lbmhip_domain_destroy(d); };
+	hipError_t e = hipStreamCreateWithFlags(&d->own_stream, hipStreamNonBlocking);
+	if (e != hipSuccess) { cleanup(); return fail("hipStreamCreate failed: %s", hipGetErrorString(e)); }
+	d->stream = d->own_stream;
+	for (int k = 0; k < 5; k++) {
+		if (d->field_bytes[k] == 0u) continue;
+		e = hipMalloc(&d->field[k], d->field_bytes[k]);
+		if (e != hipSuccess) {
+			const uint64_t need = d->N*lbmhip_bytes_per_cell_device(c->velocity_set, c->storage, c->features);
+			cleanup();
+			return fail("Grid resolution (%u, %u, %u) is too large: %llu MB required on device %d (%s).", c->Nx, c->Ny, c->Nz,
+			            (unsigned long long)(need/1048576ull), c->device, hipGetErrorString(e));
+		}
+	}
+	// defaults of LBM_Domain::allocate (lbm.cpp:164-167, 175): rho = 1, everything else 0; fi is left to initialize()
+	e = hipMemsetAsync(d->field[LBMHIP_FIELD_FI], 0, d->field_bytes[LBMHIP_FIELD_FI], d->stream);
+	if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)d->field[LBMHIP_FIELD_RHO], 0x3F800000, d->N, d->stream);
+	if (e == hipSuccess) e = hipMemsetAsync(d->field[LBMHIP_FIELD_U], 0, d->field_bytes[LBMHIP_FIELD_U], d->stream);
+	if (e == hipSuccess) e = hipMemsetAsync(d->field[LBMHIP_FIELD_FLAGS], 0, d->field_bytes[LBMHIP_FIELD_FLAGS], d->stream);
+	if (e == hipSuccess && d->field[LBMHIP_FIELD_F]) e = hipMemsetAsync(d->field[LBMHIP_FIELD_F], 0, d->field_bytes[LBMHIP_FIELD_F], d->stream);
+	if (e != hipSuccess) { cleanup(); return fail("clearing the fields failed: %s", hipGetErrorString(e)); }
+
+	if (c->Dx*c->Dy*c->Dz > 1u) { // LBM_Domain::allocate_transfer (lbm.cpp:2019-2035): one set of buffers sized for the largest face
+		uint64_t amax = 0u;
+		if (c->Dx > 1u) amax = std::max<uint64_t>(amax, (uint64_t)c->Ny*c->Nz);
+		if (c->Dy > 1u) amax = std::max<uint64_t>(amax, (uint64_t)c->Nz*c->Nx);
+		if (c->Dz > 1u) amax = std::max<uint64_t>(amax, (uint64_t)c->Nx*c->Ny);
+		d->halo_capacity = amax*std::max<uint32_t>(q_transfers(c->velocity_set)*d->fpxx_bytes, 17u);
+		for (int k = 0; k < 4; k++) {
+			e = hipMalloc(&d->halo_own[k], d->halo_capacity);
+			if (e != hipSuccess) { cleanup(); return fail("allocating halo staging buffers failed: %s", hipGetErrorString(e)); }
+			d->halo[k] = d->halo_own[k];
+		}
+	}
+	e = hipEventCreate(&d->ev_start);
+	if (e == hipSuccess) e = hipEventCreate(&d->ev_stop);
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_packed, hipEventDisableTiming);
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_copied, hipEventDisableTiming);
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming);
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming);
+	if (e == hipSuccess) e = hipStreamCreateWithFlags(&d->comm_stream, hipStreamNonBlocking);
+	if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+	if (e != hipSuccess) { cleanup(); return fail("domain setup failed: %s", hipGetErrorString(e)); }
+	*out = d;
+	return 0;
+}
+
+int lbmhip_domain_destroy(lbmhip_domain* d) {
+	if (!d) return 0;
+	DeviceGuard g(d->cfg.device);
+	if (d->own_stream) (void)hipStreamSynchronize(d->own_stream);
+	for (int k = 0; k < 5; k++) if (d->field[k]) (void)hipFree(d->field[k]);
+	for (int k = 0; k < 4; k++) if (d->halo_own[k]) (void)hipFree(d->halo_own[k]);
+	if (d->ev_start) (void)hipEventDestroy(d->ev_start);
+	if (d->ev_stop) (void)hipEventDestroy(d->ev_stop);
+	if (d->ev_packed) (void)hipEventDestroy(d->ev_packed);
+	if (d->ev_copied) (void)hipEventDestroy(d->ev_copied);
+	if (d->ev_fork) (void)hipEventDestroy(d->ev_fork);
+	if (d->ev_join) (void)hipEventDestroy(d->ev_join);
+	if (d->comm_stream) { (void)hipStreamSynchronize(d->comm_stream); (void)hipStreamDestroy(d->comm_stream); }
+	if (d->own_stream) (void)hipStreamDestroy(d->own_stream);
+	delete d;
+	return 0;
+}
+int lbmhip_domain_config(const lbmhip_domain* d, lbmhip_config* out) {
+	NEED(d && out, "lbmhip_domain_config: null argument");
+	*out = d->cfg;
+	return 0;
+}
+
+int lbmhip_set_stream(lbmhip_domain* d, void* stream) {
+	NEED(d, "null domain");
+	d->stream = stream ? (hipStream_t)stream : d->own_stream;
+	return 0;
+}
+int lbmhip_get_stream(lbmhip_domain* d, void** stream) {
+	NEED(d && stream, "null argument");
+	*stream = (void*)d->stream;
+	return 0;
+}
+int lbmhip_sync(lbmhip_domain* d) {
+	NEED(d, "null domain");
+	DeviceGuard g(d->cfg.device);
+	HIP_TRY(hipStreamSynchronize(d->stream));
+	if (d->saved_stream) HIP_TRY(hipStreamSynchronize(d->saved_stream));
+	if (d->comm_stream != d->stream) HIP_TRY(hipStreamSynchronize(d->comm_stream));
+	return 0;
+}
+int lbmhip_comm_begin(lbmhip_domain* d) {
+	NEED(d, "null domain");
+	NEED(!d->saved_stream, "lbmhip_comm_begin: already on the communication stream");
+	DeviceGuard g(d->cfg.device);
+	HIP_TRY(hipEventRecord(d->ev_fork, d->stream));
+	HIP_TRY(hipStreamWaitEvent(d->comm_stream, d->ev_fork, 0));
+	d->saved_stream = d->stream;
+	d->stream = d->comm_stream;
+	return 0;
+}
+int lbmhip_comm_end(lbmhip_domain* d) {
+	NEED(d, "null domain");
+	NEED(d->saved_stream, "lbmhip_comm_end without lbmhip_comm_begin");
+	d->stream = d->saved_stream;
+	d->saved_stream = nullptr;
+	return 0;
+}
+int lbmhip_comm_join(lbmhip_domain* d) {
+	NEED(d, "null domain");
+	NEED(!d->saved_stream, "lbmhip_comm_join: call lbmhip_comm_end first");
+	DeviceGuard g(d->cfg.device);
+	HIP_TRY(hipEventRecord(d->ev_join, d->comm_stream));
+	HIP_TRY(hipStreamWaitEvent(d->stream, d->ev_join, 0));
+	return 0;
+}
+
+int lbmhip_upload(lbmhip_domain* d, int field, const void* host, uint64_t offset, uint64_t bytes) {
+	NEED(d && host, "null argument");
+	NEED(field >= 0 && field < 5 && d->field[field], "field %d does not exist in this domain", field);
+	NEED(offset+bytes <= d->field_bytes[field], "upload of %llu bytes at offset %llu exceeds field %d (%llu bytes)",
+	     (unsigned long long)bytes, (unsigned long long)offset, field, (unsigned long long)d->field_bytes[field]);
+	DeviceGuard g(d->cfg.device);
+	HIP_TRY(hipMemcpyAsync((char*)d->field[field]+offset, host, bytes, hipMemcpyHostToDevice, d->stream));
+	HIP_TRY(hipStreamSynchronize(d->stream));
+	return 0;
+}
+int lbmhip_download(lbmhip_domain* d, int field, void* host, uint64_t offset, uint64_t bytes) {
+	NEED(d && host, "null argument");
+	NEED(field >= 0 && field < 5 && d->field[field], "field %d does not exist in this domain", field);
+	NEED(offset+bytes <= d->field_bytes[field], "download of %llu bytes at offset %llu exceeds field %d (%llu bytes)",
+	     (unsigned long long)bytes, (unsigned long long)offset, field, (unsigned long long)d->field_bytes[field]);
+	DeviceGuard g(d->cfg.device);
+	HIP_TRY(hipMemcpyAsync(host, (const char*)d->field[field]+offset, bytes, hipMemcpyDeviceToHost, d->stream));
+	HIP_TRY(hipStreamSynchronize(d->stream));
+	return 0;
+}
+int lbmhip_field_pointer(lbmhip_domain* d, int field, void** p, uint64_t* bytes) {
+	NEED(d && p, "null argument");
+	NEED(field >= 0 && field < 5 && d->field[field], "field %d does not exist in this domain", field);
+	*p = d->field[field];
+	if (bytes) *bytes = d->field_bytes[field];
+	return 0;
+}
+
+int lbmhip_set_tuning(lbmhip_domain* d, const char* key, int value) {
+	NEED(d && key, "null argument");
+	if (!strcmp(key, "cells_per_thread")) { NEED(value == 0 || value == 1 || value == 2 || value == 4, "cells_per_thread must be 0 (auto), 1, 2 or 4"); d->cells_per_thread = value; return 0; }
+	if (!strcmp(key, "block")) { NEED(value == 0 || (value >= 64 && value <= 256 && value%64 == 0), "block must be 0 (auto), 64, 128, 192 or 256"); d->block = value; return 0; }
+	return fail("unknown tuning key '%s'", key);
+}
+
+} // extern "C"
+
+// ---------------------------------------------------------------------------------------------- launches
+static collide_launch_fn find_collide(const lbmhip_domain* d, int V, bool fields_only) {
+	const int Q = (int)d->cfg.velocity_set, ST = (int)d->cfg.storage, COLL = (int)d->cfg.collision;
+	collide_launch_fn fn = nullptr;
+	for (int pass = 0; pass < 2 && !fn; pass++) { // pass 0: instance specialised for exactly this feature set; pass 1: run-time features
+		const int FEAT = (pass == 0 && !fields_only) ? (int)d->cfg.features : -1;
+		if (Q == 19) fn = ST == ST_FP32 ? select_collide_q19_fp32(COLL, FEAT, V, fields_only) : ST == ST_FP16S ? select_collide_q19_fp16s(COLL, FEAT, V, fields_only) : select_collide_q19_fp16c(COLL, FEAT, V, fields_only);
+		else if (Q == 27) fn = ST == ST_FP32 ? select_collide_q27_fp32(COLL, FEAT, V, fields_only) : ST == ST_FP16S ? select_collide_q27_fp16s(COLL, FEAT, V, fields_only) : select_collide_q27_fp16c(COLL, FEAT, V, fields_only);
+		else fn = select_collide_small(Q, ST, COLL, FEAT, V, fields_only);
+	}
+	return fn;
+}
+
+static int launch_collide_planes(lbmhip_domain* d, uint64_t t, float fx, float fy, float fz, uint32_t z0, uint32_t z1, bool fields_only) {
+	const uint32_t hz = d->cfg.Dz > 1u;
+	if (z0 < hz) z0 = hz;
+	if (z1 > d->cfg.Nz-hz) z1 = d->cfg.Nz-hz;
+	if (z0 >= z1) return 0;
+	int V = fields_only ? 1 : d->cells_per_thread;
+	const bool small = d->cfg.velocity_set == 9u || d->cfg.velocity_set == 15u;
+	if (V == 0) V = small ? 1 : (d->cfg.storage == LBMHIP_FP32 ? 2 : 4);
+	if (small) V = 1;
+	while (V > 1 && d->cfg.Nx%(uint32_t)V != 0u) V /= 2; // vector accesses need rows that are whole vectors
+	const uint32_t lanes_per_row = (d->cfg.Nx+(uint32_t)V-1u)/(uint32_t)V;
+	uint32_t block = d->block ? (uint32_t)d->block : 256u;
+	const uint32_t need = (lanes_per_row+63u)/64u*64u;
+	if (block > need) block = need;
+	Args a = make_args(d, t, fx, fy, fz);
+	a.z0 = z0; a.z1 = z1;
+	a.xchunks = (lanes_per_row+block-1u)/block;
+	const uint64_t blocks = (uint64_t)a.xchunks*d->cfg.Ny*(z1-z0);
+	NEED(blocks <= 0x7FFFFFFFull, "lattice too large for one launch (%llu workgroups)", (unsigned long long)blocks);
+	collide_launch_fn fn = find_collide(d, V, fields_only);
+	NEED(fn, "no compiled kernel for D?Q%u storage %u collision %u", d->cfg.velocity_set, d->cfg.storage, d->cfg.collision);
+	DeviceGuard g(d->cfg.device);
+	HIP_TRY(fn(a, dim3((uint32_t)blocks), dim3(block), d->stream));
+	return 0;
+}
+
+#define DISPATCH_Q_ST(Q_, ST_, CALL) \
+	switch (Q_) { \
+		case 9:  switch (ST_) { case ST_FP32: { constexpr int Q = 9,  ST = ST_FP32; CALL; } break; case ST_FP16S: { constexpr int Q = 9,  ST = ST_FP16S; CALL; } break; default: { constexpr int Q = 9,  ST = ST_FP16C; CALL; } break; } break; \
+		case 15: switch (ST_) { case ST_FP32: { constexpr int Q = 15, ST = ST_FP32; CALL; } break; case ST_FP16S: { constexpr int Q = 15, ST = ST_FP16S; CALL; } break; default: { constexpr int Q = 15, ST = ST_FP16C; CALL; } break; } break; \
+		case 19: switch (ST_) { case ST_FP32: { constexpr int Q = 19, ST = ST_FP32; CALL; } break; case ST_FP16S: { constexpr int Q = 19, ST = ST_FP16S; CALL; } break; default: { constexpr int Q = 19, ST = ST_FP16C; CALL; } break; } break; \
+		default: switch (ST_) { case ST_FP32: { constexpr int Q = 27, ST = ST_FP32; CALL; } break; case ST_FP16S: { constexpr int Q = 27, ST = ST_FP16S; CALL; } break; default: { constexpr int Q = 27, ST = ST_FP16C; CALL; } break; } break; \
+	}
+
+static dim3 grid_for(uint64_t n, uint32_t block) { return dim3((uint32_t)((n+block-1u)/block)); }
+
+extern "C" {
+
+int lbmhip_initialize(lbmhip_domain* d) {
+	NEED(d, "null domain");
+	DeviceGuard g(d->cfg.device);
+	const Args a = make_args(d, 1u, 0.0f, 0.0f, 0.0f);
+	DISPATCH_Q_ST((int)d->cfg.velocity_set, (int)d->cfg.storage, hipLaunchKernelGGL((k_initialize<Q, ST>), grid_for(d->N, 256u), dim3(256), 0, d->stream, a));
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+int lbmhip_stream_collide(lbmhip_domain* d, uint64_t t, float fx, float fy, float fz) {
+	NEED(d, "null domain");
+	return launch_collide_planes(d, t, fx, fy, fz, 0u, d->cfg.Nz, false);
+}
+int lbmhip_stream_collide_planes(lbmhip_domain* d, uint64_t t, float fx, float fy, float fz, uint32_t z_begin, uint32_t z_end) {
+	NEED(d, "null domain");
+	NEED(z_begin <= z_end && z_end <= d->cfg.Nz, "plane range [%u, %u) outside the lattice (Nz=%u)", z_begin, z_end, d->cfg.Nz);
+	return launch_collide_planes(d, t, fx, fy, fz, z_begin, z_end, false);
+}
+int lbmhip_update_fields(lbmhip_domain* d, uint64_t t, float fx, float fy, float fz) {
+	NEED(d, "null domain");
+	return launch_collide_planes(d, t, fx, fy, fz, 0u, d->cfg.Nz, true);
+}
+int lbmhip_update_force_field(lbmhip_domain* d, uint64_t t) {
+	NEED(d, "null domain");
+	NEED(d->field[LBMHIP_FIELD_F], "update_force_field needs the FORCE_FIELD extension");
+	DeviceGuard g(d->cfg.device);
+	const Args a = make_args(d, t, 0.0f, 0.0f, 0.0f);
+	DISPATCH_Q_ST((int)d->cfg.velocity_set, (int)d->cfg.storage, hipLaunchKernelGGL((k_update_force_field<Q, ST>), grid_for(d->N, 256u), dim3(256), 0, d->stream, a));
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+int lbmhip_reset_force_field(lbmhip_domain* d) {
+	NEED(d, "null domain");
+	NEED(d->field[LBMHIP_FIELD_F], "reset_force_field needs the FORCE_FIELD extension");
+	DeviceGuard g(d->cfg.device);
+	const Args a = make_args(d, 0u, 0.0f, 0.0f, 0.0f);
+	hipLaunchKernelGGL(k_reset_force_field, grid_for(d->N, 256u), dim3(256), 0, d->stream, a);
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+int lbmhip_update_moving_boundaries(lbmhip_domain* d) {
+	NEED(d, "null domain");
+	NEED(d->cfg.features&LBMHIP_MOVING_BOUNDARIES, "update_moving_boundaries needs the MOVING_BOUNDARIES extension");
+	DeviceGuard g(d->cfg.device);
+	const Args a = make_args(d, 0u, 0.0f, 0.0f, 0.0f);
+	switch (d->cfg.velocity_set) {
+		case 9: hipLaunchKernelGGL((k_update_moving_boundaries<9>), grid_for(d->N, 256u), dim3(256), 0, d->stream, a); break;
+		case 15: hipLaunchKernelGGL((k_update_moving_boundaries<15>), grid_for(d->N, 256u), dim3(256), 0, d->stream, a); break;
+		case 19: hipLaunchKernelGGL((k_update_moving_boundaries<19>), grid_for(d->N, 256u), dim3(256), 0, d->stream, a); break;
+		default: hipLaunchKernelGGL((k_update_moving_boundaries<27>), grid_for(d->N, 256u), dim3(256), 0, d->stream, a); break;
+	}
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- halo
+static int halo_check(const lbmhip_domain* d, int what, int axis) {
+	NEED(d, "null domain");
+	NEED(what >= LBMHIP_HALO_FI && what <= LBMHIP_HALO_F, "unknown halo content %d", what);
+	NEED(axis >= 0 && axis < 3, "axis must be 0, 1 or 2");
+	const uint32_t dd = axis == 0 ? d->cfg.Dx : axis == 1 ? d->cfg.Dy : d->cfg.Dz;
+	NEED(dd > 1u, "axis %d has a single domain and therefore no halo", axis);
+	NEED(what != LBMHIP_HALO_F || d->field[LBMHIP_FIELD_F], "halo exchange of F needs the FORCE_FIELD extension");
+	NEED(d->halo[0] && d->halo[1] && d->halo[2] && d->halo[3], "no staging buffers");
+	return 0;
+}
+static uint64_t face_area(const lbmhip_domain* d, int axis) {
+	return axis == 0 ? (uint64_t)d->cfg.Ny*d->cfg.Nz : axis == 1 ? (uint64_t)d->cfg.Nz*d->cfg.Nx : (uint64_t)d->cfg.Nx*d->cfg.Ny;
+}
+static uint32_t halo_bytes_per_cell(const lbmhip_domain* d, int what) { // lbm.cpp:2184-2194
+	return what == LBMHIP_HALO_FI ? q_transfers(d->cfg.velocity_set)*d->fpxx_bytes : what == LBMHIP_HALO_RHO_U_FLAGS ? 17u : what == LBMHIP_HALO_FLAGS ? 1u : 12u;
+}
+int lbmhip_halo_bytes(const lbmhip_domain* d, int what, int axis, uint64_t* bytes) {
+	NEED(bytes, "null argument");
+	if (halo_check(d, what, axis)) return 1;
+	*bytes = face_area(d, axis)*halo_bytes_per_cell(d, what);
+	return 0;
+}
+static int halo_launch(lbmhip_domain* d, int what, int axis, uint64_t t, bool insert) {
+	if (halo_check(d, what, axis)) return 1;
+	const uint64_t A = face_area(d, axis);
+	NEED(A*halo_bytes_per_cell(d, what) <= d->halo_capacity, "staging buffers too small (%llu bytes)", (unsigned long long)d->halo_capacity);
+	HaloArgs h;
+	h.lat = make_args(d, t, 0.0f, 0.0f, 0.0f);
+	h.buf[0] = d->halo[insert ? LBMHIP_BUF_RECV_P : LBMHIP_BUF_SEND_P];
+	h.buf[1] = d->halo[insert ? LBMHIP_BUF_RECV_M : LBMHIP_BUF_SEND_M];
+	h.axis = (uint32_t)axis; h.A = (uint32_t)A; h.insert = insert;
+	const dim3 grid((uint32_t)((A+255u)/256u), 2u), block(256);
+	DeviceGuard g(d->cfg.device);
+	if (what == LBMHIP_HALO_FI) {
+		DISPATCH_Q_ST((int)d->cfg.velocity_set, (int)d->cfg.storage, hipLaunchKernelGGL((k_halo_fi<Q, ST>), grid, block, 0, d->stream, h));
+	} else {
+		hipLaunchKernelGGL(k_halo_fields, grid, block, 0, d->stream, h, (uint32_t)what);
+	}
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+int lbmhip_halo_pack(lbmhip_domain* d, int what, int axis, uint64_t t) { return halo_launch(d, what, axis, t, false); }
+int lbmhip_halo_unpack(lbmhip_domain* d, int what, int axis, uint64_t t) { return halo_launch(d, what, axis, t, true); }
+
+int lbmhip_halo_buffer(lbmhip_domain* d, int which, void** p, uint64_t* capacity) {
+	NEED(d && p, "null argument");
+	NEED(which >= 0 && which < 4, "unknown staging buffer %d", which);
+	NEED(d->halo[which], "this domain has no staging buffers (single domain)");
+	*p = d->halo[which];
+	if (capacity) *capacity = d->halo_capacity;
+	return 0;
+}
+int lbmhip_halo_set_buffers(lbmhip_domain* d, void* send_p, void* send_m, void* recv_p, void* recv_m, uint64_t capacity) {
+	NEED(d, "null domain");
+	if (!send_p && !send_m && !recv_p && !recv_m) { // back to the library's own buffers
+		for (int k = 0; k < 4; k++) d->halo[k] = d->halo_own[k];
+		return 0;
+	}
+	NEED(send_p && send_m && recv_p && recv_m, "all four staging buffers must be given");
+	uint64_t need = 0u;
+	for (int ax = 0; ax < 3; ax++) {
+		const uint32_t dd = ax == 0 ? d->cfg.Dx : ax == 1 ? d->cfg.Dy : d->cfg.Dz;
+		if (dd > 1u) need = std::max<uint64_t>(need, face_area(d, ax)*std::max<uint32_t>(q_transfers(d->cfg.velocity_set)*d->fpxx_bytes, 17u));
+	}
+	NEED(capacity >= need, "staging buffers of %llu bytes are too small, %llu needed", (unsigned long long)capacity, (unsigned long long)need);
+	d->halo[LBMHIP_BUF_SEND_P] = send_p; d->halo[LBMHIP_BUF_SEND_M] = send_m; d->halo[LBMHIP_BUF_RECV_P] = recv_p; d->halo[LBMHIP_BUF_RECV_M] = recv_m;
+	d->halo_capacity = capacity;
+	return 0;
+}
+
+int lbmhip_halo_exchange_local(lbmhip_domain** doms, uint32_t count, int what, int axis) {
+	NEED(doms && count > 0u, "null argument");
+	const lbmhip_config& c0 = doms[0]->cfg;
+	NEED(count == c0.Dx*c0.Dy*c0.Dz, "expected %u domains, got %u", c0.Dx*c0.Dy*c0.Dz, count);
+	for (uint32_t k = 0; k < count; k++) if (halo_check(doms[k], what, axis)) return 1;
+	const uint64_t bytes = face_area(doms[0], axis)*halo_bytes_per_cell(doms[0], what);
+	for (uint32_t k = 0; k < count; k++) { // every domain's pack is complete once its own stream reaches this event
+		DeviceGuard g(doms[k]->cfg.device);
+		HIP_TRY(hipEventRecord(doms[k]->ev_packed, doms[k]->stream));
+	}
+	const uint32_t Dx = c0.Dx, Dy = c0.Dy, Dz = c0.Dz;
+	for (uint32_t k = 0; k < count; k++) {
+		uint32_t pos[3] = {(k%(Dx*Dy))%Dx, (k%(Dx*Dy))/Dx, k/(Dx*Dy)};
+		const uint32_t dd = axis == 0 ? Dx : axis == 1 ? Dy : Dz;
+		pos[axis] = (pos[axis]+1u)%dd; // periodic wrap (lbm.cpp:2130-2132)
+		lbmhip_domain* d = doms[k];
+		lbmhip_domain* p = doms[pos[0]+(pos[1]+pos[2]*Dy)*Dx];
+		{ // d's + face -> p's - halo, on p's stream
+			DeviceGuard g(p->cfg.device);
+			HIP_TRY(hipStreamWaitEvent(p->stream, d->ev_packed, 0));
+			HIP_TRY(hipMemcpyPeerAsync(p->halo[LBMHIP_BUF_RECV_M], p->cfg.device, d->halo[LBMHIP_BUF_SEND_P], d->cfg.device, bytes, p->stream));
+		}
+		{ // p's - face -> d's + halo, on d's stream
+			DeviceGuard g(d->cfg.device);
+			HIP_TRY(hipStreamWaitEvent(d->stream, p->ev_packed, 0));
+			HIP_TRY(hipMemcpyPeerAsync(d->halo[LBMHIP_BUF_RECV_P], d->cfg.device, p->halo[LBMHIP_BUF_SEND_M], p->cfg.device, bytes, d->stream));
+		}
+	}
+	// a domain may refill its send buffers only after its neighbours have copied them
+	for (uint32_t k = 0; k < count; k++) { DeviceGuard g(doms[k]->cfg.device); HIP_TRY(hipEventRecord(doms[k]->ev_copied, doms[k]->stream)); }
+	for (uint32_t k = 0; k < count; k++) {
+		DeviceGuard g(doms[k]->cfg.device);
+		for (uint32_t q = 0; q < count; q++) if (q != k) HIP_TRY(hipStreamWaitEvent(doms[k]->stream, doms[q]->ev_copied, 0));
+	}
+	return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- timing
+int lbmhip_timer_start(lbmhip_domain* d) {
+	NEED(d, "null domain");
+	DeviceGuard g(d->cfg.device);
+	HIP_TRY(hipEventRecord(d->ev_start, d->stream));
+	return 0;
+}
+int lbmhip_timer_stop(lbmhip_domain* d, float* ms) {
+	NEED(d && ms, "null argument");
+	DeviceGuard g(d->cfg.device);
+	HIP_TRY(hipEventRecord(d->ev_stop, d->stream));
+	HIP_TRY(hipEventSynchronize(d->ev_stop));
+	HIP_TRY(hipEventElapsedTime(ms, d->ev_start, d->ev_stop));
+	return 0;
+}
+
+} // extern "C"

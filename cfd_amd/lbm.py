@@ -1,0 +1,327 @@
+"""Python mirror of the reference's LBM host class over the C ABI of liblbmhip.so.
+
+Mirrors FluidX3D-master/src/lbm.hpp:208-611 / lbm.cpp:1038-1124, 1354-1500, 2120-2182: a global lattice split
+into Dx*Dy*Dz domains with 1-cell halos, host fields rho/u/flags/F, initialize(), do_time_step(), run(),
+update_fields(), read_from_device().  Only ctypes and numpy are used; all arithmetic happens in the HIP kernels.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+STORAGE = {"FP32": 0, "FP16S": 1, "FP16C": 2}
+COLLISION = {"SRT": 0, "TRT": 1}
+FEATURES = {"UPDATE_FIELDS": 1, "VOLUME_FORCE": 2, "MOVING_BOUNDARIES": 4, "EQUILIBRIUM_BOUNDARIES": 8,
+            "FORCE_FIELD": 16, "SUBGRID": 32}
+FIELD_FI, FIELD_RHO, FIELD_U, FIELD_FLAGS, FIELD_F = range(5)
+HALO_FI, HALO_RHO_U_FLAGS, HALO_FLAGS, HALO_F = range(4)
+BUF_SEND_P, BUF_SEND_M, BUF_RECV_P, BUF_RECV_M = range(4)
+TYPE_S, TYPE_E, TYPE_T, TYPE_F, TYPE_I, TYPE_G, TYPE_X, TYPE_Y, TYPE_MS = 1, 2, 4, 8, 16, 32, 64, 128, 3
+
+lib_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "liblbmhip.so")
+
+
+class LbmHipError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [("Nx", C.c_uint32), ("Ny", C.c_uint32), ("Nz", C.c_uint32), ("Dx", C.c_uint32), ("Dy", C.c_uint32),
+                ("Dz", C.c_uint32), ("Ox", C.c_int32), ("Oy", C.c_int32), ("Oz", C.c_int32), ("velocity_set", C.c_uint32),
+                ("storage", C.c_uint32), ("collision", C.c_uint32), ("features", C.c_uint32), ("nu", C.c_float),
+                ("device", C.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    """The loaded C-ABI library; raises if it has not been built (there is no fallback path)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(lib_path):
+            raise LbmHipError("%s is missing: build it with `make -C cfd_amd/csrc` (or __graft_entry__.build())" % lib_path)
+        L = C.CDLL(lib_path)
+        L.lbmhip_last_error.restype = C.c_char_p
+        L.lbmhip_version.restype = C.c_char_p
+        L.lbmhip_bytes_per_cell_device.restype = C.c_uint32
+        L.lbmhip_bandwidth_bytes_per_cell.restype = C.c_uint32
+        _lib = L
+    return _lib
+
+
+def check(status):
+    if status != 0:
+        raise LbmHipError(lib().lbmhip_last_error().decode())
+
+
+def feature_mask(features):
+    m = 0
+    for f in features:
+        m |= FEATURES[f]
+    return m
+
+
+def device_count():
+    n = C.c_int(0)
+    check(lib().lbmhip_device_count(C.byref(n)))
+    return n.value
+
+
+class Domain:
+    """One lbmhip_domain handle plus its host mirrors (the reference's LBM_Domain, lbm.hpp:20-204)."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self.h = C.c_void_p()
+        check(lib().lbmhip_domain_create(C.byref(cfg), C.byref(self.h)))
+        self.N = cfg.Nx * cfg.Ny * cfg.Nz
+        self.rho = np.ones(self.N, dtype=np.float32)
+        self.u = np.zeros(3 * self.N, dtype=np.float32)
+        self.flags = np.zeros(self.N, dtype=np.uint8)
+        self.F = np.zeros(3 * self.N, dtype=np.float32) if cfg.features & FEATURES["FORCE_FIELD"] else None
+
+    def close(self):
+        if self.h:
+            lib().lbmhip_domain_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def upload(self, field, a):
+        check(lib().lbmhip_upload(self.h, field, a.ctypes.data_as(C.c_void_p), C.c_uint64(0), C.c_uint64(a.nbytes)))
+
+    def download(self, field, a):
+        check(lib().lbmhip_download(self.h, field, a.ctypes.data_as(C.c_void_p), C.c_uint64(0), C.c_uint64(a.nbytes)))
+
+    def download_fi(self):
+        dt = np.float32 if self.cfg.storage == 0 else np.uint16
+        a = np.empty(self.N * self.cfg.velocity_set, dtype=dt)
+        self.download(FIELD_FI, a)
+        return a
+
+    def field_pointer(self, field):
+        p, n = C.c_void_p(), C.c_uint64()
+        check(lib().lbmhip_field_pointer(self.h, field, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+
+class LBM:
+    """LBM(N=(Nx,Ny,Nz), nu, D=(Dx,Dy,Dz), Q, storage, collision, features, f=(fx,fy,fz), devices=[...])
+
+    Global host fields (numpy, [z,y,x]; u and F [component,z,y,x]) are filled by the caller before run().
+    devices lists one HIP ordinal per domain; with fewer GPUs than domains every domain runs on device 0, which is
+    how the reference tests its decomposition on one device (FluidX3D-master/src/lbm.cpp:949-953, 985-989).
+    """
+
+    def __init__(self, N, nu, D=(1, 1, 1), Q=19, storage="FP32", collision="SRT", features=(), f=(0.0, 0.0, 0.0), devices=None, overlap=True):
+        L = lib()
+        D = tuple(int(v) for v in D)
+        if D[0] * D[1] * D[2] == 0:
+            raise LbmHipError("You specified 0 LBM grid domains (%dx%dx%d)." % D)
+        self.N = tuple((int(N[k]) // D[k]) * D[k] for k in range(3))  # lbm.cpp:1043-1054
+        self.D, self.Q, self.storage, self.collision, self.features, self.nu = D, Q, storage, collision, tuple(features), float(nu)
+        self.fx, self.fy, self.fz = (float(v) for v in f)
+        mask = feature_mask(features)
+        if not (mask & FEATURES["VOLUME_FORCE"]) and (self.fx != 0.0 or self.fy != 0.0 or self.fz != 0.0):
+            raise LbmHipError("Volume force is set in LBM constructor, but VOLUME_FORCE is not enabled.")  # lbm.cpp:1211-1215
+        self.H = tuple(1 if d > 1 else 0 for d in D)
+        self.local = tuple(self.N[k] // D[k] + 2 * self.H[k] for k in range(3))
+        nd = D[0] * D[1] * D[2]
+        if devices is None:
+            have = device_count()
+            devices = list(range(nd)) if have >= nd else [0] * nd
+        self.domains = []
+        try:
+            for d in range(nd):
+                x, y, z = (d % (D[0] * D[1])) % D[0], (d % (D[0] * D[1])) // D[0], d // (D[0] * D[1])
+                cfg = Config(self.local[0], self.local[1], self.local[2], D[0], D[1], D[2],
+                             x * self.N[0] // D[0] - self.H[0], y * self.N[1] // D[1] - self.H[1], z * self.N[2] // D[2] - self.H[2],
+                             Q, STORAGE[storage], COLLISION[collision], mask, self.nu, devices[d])
+                self.domains.append(Domain(cfg))
+        except Exception:
+            self.close()
+            raise
+        self._handles = (C.c_void_p * nd)(*[dom.h for dom in self.domains])
+        Nx, Ny, Nz = self.N
+        self.rho = np.ones((Nz, Ny, Nx), dtype=np.float32)
+        self.u = np.zeros((3, Nz, Ny, Nx), dtype=np.float32)
+        self.flags = np.zeros((Nz, Ny, Nx), dtype=np.uint8)
+        self.has_F = bool(mask & FEATURES["FORCE_FIELD"])
+        self.F = np.zeros((3, Nz, Ny, Nx), dtype=np.float32) if self.has_F else None
+        self.update_fields_ext = bool(mask & FEATURES["UPDATE_FIELDS"])
+        self.t = 0
+        self.initialized = False
+        self.t_last_update_fields = None
+        self.t_last_force_field = None
+        # compute/communication overlap is used for pure z-slab decompositions
+        self.overlap = bool(overlap) and D[0] == 1 and D[1] == 1 and D[2] > 1 and self.local[2] >= 5
+        self._L = L
+
+    # ---- life cycle
+    def close(self):
+        for dom in getattr(self, "domains", []):
+            dom.close()
+        self.domains = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- getters of the reference's class (lbm.hpp:454-472)
+    def get_Nx(self): return self.N[0]
+    def get_Ny(self): return self.N[1]
+    def get_Nz(self): return self.N[2]
+    def get_N(self): return self.N[0] * self.N[1] * self.N[2]
+    def get_D(self): return self.D[0] * self.D[1] * self.D[2]
+    def get_t(self): return self.t
+    def get_nu(self): return self.nu
+    def get_tau(self): return float(np.float32(3.0) * np.float32(self.nu) + np.float32(0.5))
+
+    def set_f(self, fx, fy, fz):
+        self.fx, self.fy, self.fz = float(fx), float(fy), float(fz)
+
+    def bandwidth_bytes_per_cell(self):
+        return self._L.lbmhip_bandwidth_bytes_per_cell(self.Q, STORAGE[self.storage], feature_mask(self.features))
+
+    def bytes_per_cell_device(self):
+        return self._L.lbmhip_bytes_per_cell_device(self.Q, STORAGE[self.storage], feature_mask(self.features))
+
+    def set_tuning(self, key, value):
+        for dom in self.domains:
+            check(self._L.lbmhip_set_tuning(dom.h, key.encode(), int(value)))
+
+    # ---- global <-> per-domain mapping (Memory_Container::reference, lbm.hpp:265-288)
+    def _slices(self, d):
+        Dx, Dy, Dz = self.D
+        dx, dy, dz = (d % (Dx * Dy)) % Dx, (d % (Dx * Dy)) // Dx, d // (Dx * Dy)
+        n = tuple(self.N[k] // self.D[k] for k in range(3))
+        glob = (slice(dz * n[2], (dz + 1) * n[2]), slice(dy * n[1], (dy + 1) * n[1]), slice(dx * n[0], (dx + 1) * n[0]))
+        loc = (slice(self.H[2], self.H[2] + n[2]), slice(self.H[1], self.H[1] + n[1]), slice(self.H[0], self.H[0] + n[0]))
+        return glob, loc
+
+    def _view(self, a, comps):
+        Lx, Ly, Lz = self.local
+        return a.reshape((comps, Lz, Ly, Lx)) if comps > 1 else a.reshape((Lz, Ly, Lx))
+
+    def write_to_device(self, fields=("rho", "u", "flags", "F")):
+        for d, dom in enumerate(self.domains):
+            g, l = self._slices(d)
+            al = (slice(None),)
+            if "rho" in fields:
+                self._view(dom.rho, 1)[l] = self.rho[g]; dom.upload(FIELD_RHO, dom.rho)
+            if "u" in fields:
+                self._view(dom.u, 3)[al + l] = self.u[al + g]; dom.upload(FIELD_U, dom.u)
+            if "flags" in fields:
+                self._view(dom.flags, 1)[l] = self.flags[g]; dom.upload(FIELD_FLAGS, dom.flags)
+            if "F" in fields and self.has_F:
+                self._view(dom.F, 3)[al + l] = self.F[al + g]; dom.upload(FIELD_F, dom.F)
+
+    def read_from_device(self, fields=("rho", "u", "flags", "F")):
+        """Memory_Container::read_from_device (lbm.hpp:390-396): refresh rho/u on the device first if needed."""
+        if self.initialized:
+            self.update_fields()
+        for d, dom in enumerate(self.domains):
+            g, l = self._slices(d)
+            al = (slice(None),)
+            if "rho" in fields:
+                dom.download(FIELD_RHO, dom.rho); self.rho[g] = self._view(dom.rho, 1)[l]
+            if "u" in fields:
+                dom.download(FIELD_U, dom.u); self.u[al + g] = self._view(dom.u, 3)[al + l]
+            if "flags" in fields:
+                dom.download(FIELD_FLAGS, dom.flags); self.flags[g] = self._view(dom.flags, 1)[l]
+            if "F" in fields and self.has_F:
+                dom.download(FIELD_F, dom.F); self.F[al + g] = self._view(dom.F, 3)[al + l]
+
+    # ---- halo exchange between the domains of this process (LBM::communicate_field, lbm.cpp:2120-2182)
+    def _communicate(self, what):
+        L = self._L
+        for axis in range(3):
+            if self.D[axis] <= 1:
+                continue
+            for dom in self.domains:
+                check(L.lbmhip_halo_pack(dom.h, what, axis, C.c_uint64(self.t)))
+            check(L.lbmhip_halo_exchange_local(self._handles, len(self.domains), what, axis))
+            for dom in self.domains:
+                check(L.lbmhip_halo_unpack(dom.h, what, axis, C.c_uint64(self.t)))
+
+    def sync(self):
+        for dom in self.domains:
+            check(self._L.lbmhip_sync(dom.h))
+
+    # ---- LBM::initialize (lbm.cpp:1354-1409)
+    def initialize(self):
+        L = self._L
+        self.write_to_device()
+        if self.has_F:
+            self._communicate(HALO_F)
+        self.t = 1  # the communicate calls at initialization need an odd time step
+        self._communicate(HALO_RHO_U_FLAGS)
+        for dom in self.domains:
+            check(L.lbmhip_initialize(dom.h))
+        self._communicate(HALO_RHO_U_FLAGS)
+        self._communicate(HALO_FI)
+        self.sync()
+        self.t = 0
+        self.initialized = True
+        self.t_last_update_fields = 0 if self.update_fields_ext else None
+        self.t_last_force_field = None
+
+    # ---- LBM::do_time_step (lbm.cpp:1411-1459) without the per-step host synchronisation
+    def do_time_step(self):
+        L = self._L
+        t, fx, fy, fz = C.c_uint64(self.t), C.c_float(self.fx), C.c_float(self.fy), C.c_float(self.fz)
+        if self.overlap:
+            # planes next to the halos first, their exchange on the communication streams while the rest collides
+            Lz = self.local[2]
+            for dom in self.domains:
+                check(L.lbmhip_stream_collide_planes(dom.h, t, fx, fy, fz, 1, 2))
+                check(L.lbmhip_stream_collide_planes(dom.h, t, fx, fy, fz, Lz - 2, Lz - 1))
+            for dom in self.domains:
+                check(L.lbmhip_comm_begin(dom.h))
+            self._communicate(HALO_FI)
+            for dom in self.domains:
+                check(L.lbmhip_comm_end(dom.h))
+            for dom in self.domains:
+                check(L.lbmhip_stream_collide_planes(dom.h, t, fx, fy, fz, 2, Lz - 2))
+            for dom in self.domains:
+                check(L.lbmhip_comm_join(dom.h))
+        else:
+            for dom in self.domains:
+                check(L.lbmhip_stream_collide(dom.h, t, fx, fy, fz))
+            self._communicate(HALO_FI)
+        self.t += 1
+        if self.update_fields_ext:
+            self.t_last_update_fields = self.t
+
+    def run(self, steps):
+        if not self.initialized:
+            self.initialize()
+        for _ in range(int(steps)):
+            self.do_time_step()
+        self.sync()
+
+    # ---- LBM::update_fields / enqueue_update_fields (lbm.cpp:238-246, 1491-1496)
+    def update_fields(self):
+        if not self.update_fields_ext and self.t != self.t_last_update_fields:
+            for dom in self.domains:
+                check(self._L.lbmhip_update_fields(dom.h, C.c_uint64(self.t), C.c_float(self.fx), C.c_float(self.fy), C.c_float(self.fz)))
+            self.t_last_update_fields = self.t
+        self.sync()
+
+    # ---- LBM::update_force_field (lbm.cpp:258-265, 1503-1508)
+    def update_force_field(self):
+        if self.t != self.t_last_force_field:
+            for dom in self.domains:
+                check(self._L.lbmhip_update_force_field(dom.h, C.c_uint64(self.t)))
+            self.t_last_force_field = self.t
+        self.sync()
+
+    def reset(self):
+        self.initialized = False

@@ -1,0 +1,140 @@
+/*
+ * lbmhip.h - C ABI of the MI355X lattice-Boltzmann time-step library (liblbmhip.so).
+ *
+ * This is the host<->device seam of the engine: what the reference's LBM_Domain reaches through its
+ * Device / Memory<T> / Kernel wrapper (FluidX3D-master/src/opencl.hpp:280-689) is reached here through
+ * plain C calls on an opaque domain handle.  One handle = one LBM_Domain = one lattice block on one GPU
+ * (FluidX3D-master/src/lbm.hpp:20-204).  Plain pointers and sizes only; no C++ or torch types.
+ *
+ * Conventions
+ *  - every call returns 0 on success, non-zero on failure; lbmhip_last_error() gives the message of the
+ *    last failure on the calling thread.  The reference prints and exits on every such error
+ *    (FluidX3D-master/src/utilities.hpp:4159-4166); the C++ host above this ABI does the same.
+ *  - one owner thread per handle; calls on one handle are not re-entrant.
+ *  - launches are asynchronous on the handle's stream; lbmhip_sync() waits for it.
+ *  - cell index n = x+(y+z*Ny)*Nx, DDFs fi[i*N+n], u[c*N+n], F[c*N+n] (FluidX3D-master/src/lbm.hpp:478-492,
+ *    kernel.cpp:871-873, 970-972).  Nx, Ny, Nz are the LOCAL sizes including the 1-cell halo on every axis
+ *    with more than one domain (FluidX3D-master/src/lbm.cpp:1059-1072).
+ */
+#ifndef LBMHIP_H
+#define LBMHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* DDF storage (FluidX3D-master/src/lbm.cpp:561-609): arithmetic is always FP32 */
+enum { LBMHIP_FP32 = 0, LBMHIP_FP16S = 1, LBMHIP_FP16C = 2 };
+/* collision operator (FluidX3D-master/src/kernel.cpp:1613-1651) */
+enum { LBMHIP_SRT = 0, LBMHIP_TRT = 1 };
+/* extensions, the reference's compile-time switches of the same names (FluidX3D-master/src/defines.hpp.bak) */
+enum {
+	LBMHIP_UPDATE_FIELDS = 1,
+	LBMHIP_VOLUME_FORCE = 2,
+	LBMHIP_MOVING_BOUNDARIES = 4,
+	LBMHIP_EQUILIBRIUM_BOUNDARIES = 8,
+	LBMHIP_FORCE_FIELD = 16,
+	LBMHIP_SUBGRID = 32
+};
+/* device fields of a domain (FluidX3D-master/src/lbm.hpp:38, 70-75) */
+enum { LBMHIP_FIELD_FI = 0, LBMHIP_FIELD_RHO = 1, LBMHIP_FIELD_U = 2, LBMHIP_FIELD_FLAGS = 3, LBMHIP_FIELD_F = 4 };
+/* what a halo exchange moves (FluidX3D-master/src/lbm.hpp:18, lbm.cpp:2184-2194) */
+enum { LBMHIP_HALO_FI = 0, LBMHIP_HALO_RHO_U_FLAGS = 1, LBMHIP_HALO_FLAGS = 2, LBMHIP_HALO_F = 3 };
+/* staging buffers of a domain: what it sends from its +/- face, what it receives for its +/- halo */
+enum { LBMHIP_BUF_SEND_P = 0, LBMHIP_BUF_SEND_M = 1, LBMHIP_BUF_RECV_P = 2, LBMHIP_BUF_RECV_M = 3 };
+
+typedef struct lbmhip_domain lbmhip_domain; /* opaque */
+
+/* constructor arguments of LBM_Domain (FluidX3D-master/src/lbm.cpp:120-160) plus what the reference bakes
+ * into the kernel text at run time (FluidX3D-master/src/lbm.cpp:424-665) */
+typedef struct lbmhip_config {
+	uint32_t Nx, Ny, Nz;   /* local lattice size including halo layers */
+	uint32_t Dx, Dy, Dz;   /* number of domains per axis (halo on an axis iff D>1) */
+	int32_t Ox, Oy, Oz;    /* offset of this domain in the global lattice */
+	uint32_t velocity_set; /* 9 (D2Q9), 15, 19 or 27 */
+	uint32_t storage;      /* LBMHIP_FP32 / FP16S / FP16C */
+	uint32_t collision;    /* LBMHIP_SRT / LBMHIP_TRT */
+	uint32_t features;     /* OR of the extension bits */
+	float nu;              /* kinematic shear viscosity; relaxation rate w = 1/(3 nu + 1/2) */
+	int32_t device;        /* HIP device ordinal */
+} lbmhip_config;
+
+/* ---- devices and errors: replaces get_devices() / print_error (opencl.hpp:234-241, utilities.hpp:4159) */
+int lbmhip_device_count(int* count);
+int lbmhip_device_name(int device, char* name, uint64_t capacity);
+int lbmhip_device_memory(int device, uint64_t* free_bytes, uint64_t* total_bytes);
+const char* lbmhip_last_error(void);
+const char* lbmhip_version(void);
+
+/* ---- byte models: bytes_per_cell_device() / bandwidth_bytes_per_cell_device() (lbm.cpp:37-82) */
+uint32_t lbmhip_bytes_per_cell_device(uint32_t velocity_set, uint32_t storage, uint32_t features);
+uint32_t lbmhip_bandwidth_bytes_per_cell(uint32_t velocity_set, uint32_t storage, uint32_t features);
+
+/* ---- domain life cycle: LBM_Domain::LBM_Domain + allocate() / ~LBM (lbm.cpp:120-229, 1125-1133).
+ * Allocates fi, rho (=1), u (=0), flags (=0), F (=0, with FORCE_FIELD) and, when any D>1, the four staging
+ * buffers.  Creates the handle's own stream. */
+int lbmhip_domain_create(const lbmhip_config* config, lbmhip_domain** out);
+int lbmhip_domain_destroy(lbmhip_domain* domain);
+int lbmhip_domain_config(const lbmhip_domain* domain, lbmhip_config* out);
+
+/* ---- streams: the in-order queue of Device (opencl.hpp:306, 330).  stream = a hipStream_t; NULL restores
+ * the handle's own stream.  All following launches and copies of this handle go to that stream. */
+int lbmhip_set_stream(lbmhip_domain* domain, void* stream);
+int lbmhip_get_stream(lbmhip_domain* domain, void** stream);
+int lbmhip_sync(lbmhip_domain* domain); /* Device::finish_queue (opencl.hpp:330) */
+/* Second in-order queue of the handle for halo traffic (no counterpart in the reference, which runs pack, copy and
+ * unpack on the one queue and blocks the host between them, lbm.cpp:2120-2182).
+ * comm_begin: the communication stream waits for everything enqueued so far, and all following launches and copies
+ * of this handle go to it; comm_end: back to the compute stream (no wait); comm_join: the compute stream waits for
+ * everything enqueued so far on the communication stream. */
+int lbmhip_comm_begin(lbmhip_domain* domain);
+int lbmhip_comm_end(lbmhip_domain* domain);
+int lbmhip_comm_join(lbmhip_domain* domain);
+
+/* ---- host <-> device copies: Memory<T>::enqueue_write_to_device / enqueue_read_from_device with offset
+ * and length (opencl.hpp:505-526, 603-606).  Offsets and sizes in bytes; the copy is complete when the call returns. */
+int lbmhip_upload(lbmhip_domain* domain, int field, const void* host, uint64_t offset, uint64_t bytes);
+int lbmhip_download(lbmhip_domain* domain, int field, void* host, uint64_t offset, uint64_t bytes);
+/* device address and size of a field, for callers that keep data resident (no copy) */
+int lbmhip_field_pointer(lbmhip_domain* domain, int field, void** device_pointer, uint64_t* bytes);
+
+/* ---- kernels: LBM_Domain::enqueue_* (lbm.cpp:231-265, 305-311) */
+int lbmhip_initialize(lbmhip_domain* domain);                                              /* kernel.cpp:1364-1446 */
+int lbmhip_stream_collide(lbmhip_domain* domain, uint64_t t, float fx, float fy, float fz); /* kernel.cpp:1470-1654 */
+/* the same step restricted to lattice planes z in [z_begin, z_end) (local coordinates); lets a caller run the
+ * planes next to a halo first and overlap their exchange with the rest.  Cells are independent within a step. */
+int lbmhip_stream_collide_planes(lbmhip_domain* domain, uint64_t t, float fx, float fy, float fz, uint32_t z_begin, uint32_t z_end);
+int lbmhip_update_fields(lbmhip_domain* domain, uint64_t t, float fx, float fy, float fz); /* kernel.cpp:1812-1894 */
+int lbmhip_update_force_field(lbmhip_domain* domain, uint64_t t);                          /* kernel.cpp:1897-1910 */
+int lbmhip_reset_force_field(lbmhip_domain* domain);                                       /* kernel.cpp:1911-1917 */
+int lbmhip_update_moving_boundaries(lbmhip_domain* domain);                                /* kernel.cpp:1449-1465 */
+
+/* ---- halo exchange: transfer_extract_* / transfer__insert_* (kernel.cpp:2130-2223) and
+ * LBM_Domain::enqueue_transfer_extract_field / insert_field (lbm.cpp:2092-2119).  axis: 0=x, 1=y, 2=z.
+ * pack fills SEND_P from the layer next to the + halo and SEND_M from the layer next to the - halo;
+ * unpack writes RECV_P into the + halo layer and RECV_M into the - halo layer.  Buffer layout buf[b*A+a]. */
+int lbmhip_halo_pack(lbmhip_domain* domain, int what, int axis, uint64_t t);
+int lbmhip_halo_unpack(lbmhip_domain* domain, int what, int axis, uint64_t t);
+int lbmhip_halo_bytes(const lbmhip_domain* domain, int what, int axis, uint64_t* bytes);
+int lbmhip_halo_buffer(lbmhip_domain* domain, int which, void** device_pointer, uint64_t* capacity);
+/* use caller-owned device memory (e.g. buffers registered with a communication library) as staging buffers */
+int lbmhip_halo_set_buffers(lbmhip_domain* domain, void* send_p, void* send_m, void* recv_p, void* recv_m, uint64_t capacity);
+/* the pointer swap of LBM::communicate_field (lbm.cpp:2129-2136) for domains that live in ONE process: copies
+ * SEND_P of every domain into RECV_M of its + neighbour and SEND_M of that neighbour into RECV_P, device to
+ * device (peer copies over xGMI when the domains sit on different GPUs), with periodic wrap.  domains[] is
+ * ordered d = x+(y+z*Dy)*Dx.  Orders the copies after each domain's pack and before its unpack. */
+int lbmhip_halo_exchange_local(lbmhip_domain** domains, uint32_t count, int what, int axis);
+
+/* ---- timing on the handle's stream (the reference only has a host clock, lbm.cpp:1481-1483) */
+int lbmhip_timer_start(lbmhip_domain* domain);
+int lbmhip_timer_stop(lbmhip_domain* domain, float* milliseconds); /* waits for the stream */
+
+/* ---- tuning knobs (no counterpart in the reference): "cells_per_thread" (1, 2 or 4), "block" (64..1024) */
+int lbmhip_set_tuning(lbmhip_domain* domain, const char* key, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LBMHIP_H */
