@@ -99,19 +99,19 @@ template <> struct Store<ST_FP16S> {
 // FP16C: 1 sign, 4 exponent (bias 15), 11 mantissa bits, subnormals below 2^-14 (kernel.cpp:858-869)
 template <> struct Store<ST_FP16C> {
 	using raw = uint16_t;
+	// exponent and mantissa moved into the FP32 fields give x*2^-112 (an FP32 subnormal when e=0); the multiply by
+	// 2^112 is exact and normalises both cases, so no branch is needed (FP32 subnormals are kept in the default mode)
 	static __device__ __forceinline__ float decode(raw r) {
-		const uint32_t h = r, s = (h&0x8000u)<<16, e = (h>>11)&0xFu, m = h&0x7FFu;
-		const uint32_t lead = 31u-(uint32_t)__clz((int)(m|1u)); // leading one of the mantissa (subnormal case)
-		const uint32_t normal = ((e+112u)<<23)|(m<<12);
-		const uint32_t subnormal = m != 0u ? ((lead+102u)<<23)|((m<<(23u-lead))&0x007FF000u) : 0u;
-		return __uint_as_float(s|(e != 0u ? normal : subnormal));
+		const uint32_t h = r;
+		const float v = __uint_as_float((h&0x7FFFu)<<12)*0x1p112f;
+		return __uint_as_float(__float_as_uint(v)|((h&0x8000u)<<16));
 	}
+	// round by adding half of the last kept mantissa bit and truncating; subnormal results restore the implicit one first
 	static __device__ __forceinline__ raw encode(float x) {
-		const uint32_t b = __float_as_uint(x)+0x00000800u;
-		const uint32_t s = (b&0x80000000u)>>16, e = (b&0x7F800000u)>>23, m = b&0x007FFFFFu;
-		const uint32_t normal = (((e-112u)<<11)&0x7800u)|(m>>12);
-		const uint32_t subnormal = ((((0x007FF800u+m)>>((124u-e)&31u))+1u)>>1);
-		return (raw)(s|(e > 112u ? normal : e > 100u ? subnormal : 0u));
+		const uint32_t b = __float_as_uint(x)+0x00000800u, a = b&0x7FFFFFFFu, e = a>>23;
+		const uint32_t normal = ((a>>12)-0x38000u)&0x7FFFu;
+		const uint32_t subnormal = ((((0x007FF800u+(a&0x007FFFFFu))>>((124u-e)&31u))+1u)>>1);
+		return (raw)(((b>>16)&0x8000u)|(e > 112u ? normal : e > 100u ? subnormal : 0u));
 	}
 };
 

@@ -5,11 +5,11 @@
 
 namespace lbm {
 
-typedef hipError_t (*collide_launch_fn)(const Args&, dim3 grid, dim3 block, hipStream_t stream);
+typedef hipError_t (*collide_launch_fn)(const Args&, dim3 grid, dim3 block, uint32_t lds_bytes, hipStream_t stream);
 
 template <int Q, int ST, int COLL, int FEAT, int V, bool FO>
-hipError_t launch_collide(const Args& a, dim3 grid, dim3 block, hipStream_t stream) {
-	hipLaunchKernelGGL((k_collide<Q, ST, COLL, FEAT, V, FO>), grid, block, 0, stream, a);
+hipError_t launch_collide(const Args& a, dim3 grid, dim3 block, uint32_t lds_bytes, hipStream_t stream) {
+	hipLaunchKernelGGL((k_collide<Q, ST, COLL, FEAT, V, FO>), grid, block, lds_bytes, stream, a);
 	return hipGetLastError();
 }
 

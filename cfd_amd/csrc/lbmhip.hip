@@ -36,7 +36,7 @@ struct lbmhip_domain {
 	void* halo[4];
 	uint64_t halo_capacity;
 	hipEvent_t ev_start, ev_stop, ev_packed, ev_copied;
-	int cells_per_thread, block;
+	int cells_per_thread, block, blocks_per_cu;
 	float w;
 };
 
@@ -133,6 +133,7 @@ int lbmhip_domain_create(const lbmhip_config* c, lbmhip_domain** out) {
 	d->w = 1.0f/(3.0f*c->nu+0.5f); // relaxation rate, float like LBM_Domain::get_tau (lbm.hpp:132, lbm.cpp:509-511)
 	d->cells_per_thread = 0; // 0 = automatic
 	d->block = 0;
+	d->blocks_per_cu = -1; // -1 = automatic
 	d->field_bytes[LBMHIP_FIELD_FI] = d->N*c->velocity_set*d->fpxx_bytes;
 	d->field_bytes[LBMHIP_FIELD_RHO] = d->N*4u;
 	d->field_bytes[LBMHIP_FIELD_U] = d->N*12u;
@@ -284,6 +285,7 @@ int lbmhip_field_pointer(lbmhip_domain* d, int field, void** p, uint64_t* bytes)
 int lbmhip_set_tuning(lbmhip_domain* d, const char* key, int value) {
 	NEED(d && key, "null argument");
 	if (!strcmp(key, "cells_per_thread")) { NEED(value == 0 || value == 1 || value == 2 || value == 4, "cells_per_thread must be 0 (auto), 1, 2 or 4"); d->cells_per_thread = value; return 0; }
+	if (!strcmp(key, "blocks_per_cu")) { NEED(value >= -1 && value <= 32, "blocks_per_cu must be -1 (auto), 0 (no limit) or 1..32"); d->blocks_per_cu = value; return 0; }
 	if (!strcmp(key, "block")) { NEED(value == 0 || (value >= 64 && value <= 256 && value%64 == 0), "block must be 0 (auto), 64, 128, 192 or 256"); d->block = value; return 0; }
 	return fail("unknown tuning key '%s'", key);
 }
@@ -308,15 +310,20 @@ static int launch_collide_planes(lbmhip_domain* d, uint64_t t, float fx, float f
 	if (z0 < hz) z0 = hz;
 	if (z1 > d->cfg.Nz-hz) z1 = d->cfg.Nz-hz;
 	if (z0 >= z1) return 0;
-	int V = fields_only ? 1 : d->cells_per_thread;
+	// Launch geometry.  Measured on MI355X at 512^3: FP32 is fastest with one cell per lane (dword accesses), 256-lane
+	// workgroups and at most 12 waves resident per CU (more waves in flight lower the achieved HBM bandwidth by ~15 %);
+	// FP16S wants 2 cells per lane (dword accesses again), FP16C (conversion-heavy) 1; neither gains from a residency cap.
 	const bool small = d->cfg.velocity_set == 9u || d->cfg.velocity_set == 15u;
-	if (V == 0) V = small ? 1 : (d->cfg.storage == LBMHIP_FP32 ? 2 : 4);
+	int V = fields_only ? 1 : d->cells_per_thread;
+	if (V == 0) V = d->cfg.storage == LBMHIP_FP16S ? 2 : 1;
 	if (small) V = 1;
 	while (V > 1 && d->cfg.Nx%(uint32_t)V != 0u) V /= 2; // vector accesses need rows that are whole vectors
 	const uint32_t lanes_per_row = (d->cfg.Nx+(uint32_t)V-1u)/(uint32_t)V;
 	uint32_t block = d->block ? (uint32_t)d->block : 256u;
 	const uint32_t need = (lanes_per_row+63u)/64u*64u;
 	if (block > need) block = need;
+	int blocks_per_cu = d->blocks_per_cu;
+	if (blocks_per_cu < 0) blocks_per_cu = (d->cfg.storage == LBMHIP_FP32 && !fields_only) ? (int)std::max(1u, 12u/(block/64u)) : 0;
 	Args a = make_args(d, t, fx, fy, fz);
 	a.z0 = z0; a.z1 = z1;
 	a.xchunks = (lanes_per_row+block-1u)/block;
@@ -325,7 +332,9 @@ static int launch_collide_planes(lbmhip_domain* d, uint64_t t, float fx, float f
 	collide_launch_fn fn = find_collide(d, V, fields_only);
 	NEED(fn, "no compiled kernel for D?Q%u storage %u collision %u", d->cfg.velocity_set, d->cfg.storage, d->cfg.collision);
 	DeviceGuard g(d->cfg.device);
-	HIP_TRY(fn(a, dim3((uint32_t)blocks), dim3(block), d->stream));
+	// dynamic LDS is not used by the kernel; reserving it caps the workgroups resident per CU (160 KiB LDS per CU)
+	const uint32_t lds = blocks_per_cu > 0 ? ((160u*1024u/(uint32_t)blocks_per_cu)&~255u) : 0u;
+	HIP_TRY(fn(a, dim3((uint32_t)blocks), dim3(block), lds, d->stream));
 	return 0;
 }
 

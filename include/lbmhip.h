@@ -131,7 +131,8 @@ int lbmhip_halo_exchange_local(lbmhip_domain** domains, uint32_t count, int what
 int lbmhip_timer_start(lbmhip_domain* domain);
 int lbmhip_timer_stop(lbmhip_domain* domain, float* milliseconds); /* waits for the stream */
 
-/* ---- tuning knobs (no counterpart in the reference): "cells_per_thread" (1, 2 or 4), "block" (64..1024) */
+/* ---- tuning knobs (no counterpart in the reference): "cells_per_thread" (0 = auto, 1, 2, 4), "block" (0 = auto,
+ * 64..256 threads), "blocks_per_cu" (-1 = auto, 0 = no limit; caps the workgroups resident per compute unit) */
 int lbmhip_set_tuning(lbmhip_domain* domain, const char* key, int value);
 
 #ifdef __cplusplus

@@ -1,0 +1,159 @@
+// Access-pattern ceilings on MI355X for the esoteric-pull DDF traffic (diagnostic tool, not part of the product).
+// Measures, on a lattice of n^3 cells with Q SoA streams: (a) a plain float4 copy, (b) in-place read-modify-write
+// of Q aligned streams with V cells per lane, (c) the same with the LBM's row/plane shifted neighbour slots.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+__global__ __launch_bounds__(256) void k_copy(const float4* __restrict__ a, float4* __restrict__ b, size_t n4) {
+	for (size_t i = (size_t)blockIdx.x*blockDim.x+threadIdx.x; i < n4; i += (size_t)gridDim.x*blockDim.x) b[i] = a[i];
+}
+// copy with U independent 16-byte loads in flight per lane; NT uses non-temporal accesses
+typedef float f4 __attribute__((ext_vector_type(4)));
+template <int U, bool NT> __global__ __launch_bounds__(256) void k_copy_u(const float4* __restrict__ a_, float4* __restrict__ b_, size_t n4) {
+	const f4* a = (const f4*)a_; f4* b = (f4*)b_;
+	const size_t base = (size_t)blockIdx.x*blockDim.x*U+threadIdx.x;
+	f4 t[U];
+#pragma unroll
+	for (int k = 0; k < U; k++) { const size_t i = base+(size_t)k*blockDim.x; if (i < n4) t[k] = NT ? __builtin_nontemporal_load(a+i) : a[i]; }
+#pragma unroll
+	for (int k = 0; k < U; k++) { const size_t i = base+(size_t)k*blockDim.x; if (i < n4) { if (NT) __builtin_nontemporal_store(t[k], b+i); else b[i] = t[k]; } }
+}
+template <int U> __global__ __launch_bounds__(256) void k_read_u(const float4* __restrict__ a, float* out, size_t n4) {
+	const size_t base = (size_t)blockIdx.x*blockDim.x*U+threadIdx.x;
+	float s = 0.0f;
+#pragma unroll
+	for (int k = 0; k < U; k++) { const size_t i = base+(size_t)k*blockDim.x; if (i < n4) { const float4 t = a[i]; s += t.x+t.y+t.z+t.w; } }
+	if (s == 123.456f) out[0] = s;
+}
+template <int U> __global__ __launch_bounds__(256) void k_write_u(float4* __restrict__ b, size_t n4, float v) {
+	const size_t base = (size_t)blockIdx.x*blockDim.x*U+threadIdx.x;
+#pragma unroll
+	for (int k = 0; k < U; k++) { const size_t i = base+(size_t)k*blockDim.x; if (i < n4) b[i] = make_float4(v, v, v, v); }
+}
+// in-place update of ONE stream: every 16-byte word is read and written back by the same lane
+template <int U> __global__ __launch_bounds__(256) void k_inplace_u(float4* __restrict__ b, size_t n4, float v) {
+	const size_t base = (size_t)blockIdx.x*blockDim.x*U+threadIdx.x;
+	float4 t[U];
+#pragma unroll
+	for (int k = 0; k < U; k++) { const size_t i = base+(size_t)k*blockDim.x; if (i < n4) t[k] = b[i]; }
+#pragma unroll
+	for (int k = 0; k < U; k++) { const size_t i = base+(size_t)k*blockDim.x; if (i < n4) { t[k].x *= v; t[k].y += v; b[i] = t[k]; } }
+}
+template <int V> struct Vec { typedef float type __attribute__((ext_vector_type(V))); };
+template <> struct Vec<1> { typedef float type; };
+
+// MODE 0: all streams aligned at the own cell. MODE 1: odd streams of each pair at the neighbour (x+cx, y+cy, z+cz) like D3Q19.
+template <int V, int MODE, bool NT, bool NTS = NT> __global__ __launch_bounds__(1024) void k_rmw(float* fi, size_t N, unsigned Nx, unsigned Ny, unsigned Nz, unsigned xchunks, float s) {
+	typedef typename Vec<V>::type vec;
+	const unsigned chunk = blockIdx.x%xchunks, r = blockIdx.x/xchunks, z = r/Ny, y = r%Ny;
+	const unsigned x = (chunk*blockDim.x+threadIdx.x)*V;
+	if (x >= Nx) return;
+	const unsigned yq[3] = {y, y+1 == Ny ? 0 : y+1, y == 0 ? Ny-1 : y-1}, zq[3] = {z, z+1 == Nz ? 0 : z+1, z == 0 ? Nz-1 : z-1};
+	const size_t row0 = ((size_t)z*Ny+y)*Nx;
+	constexpr int cx[9] = {1,0,0,1,1,0,1,1,0}, cy[9] = {0,1,0,1,0,1,-1,0,1}, cz[9] = {0,0,1,0,1,1,0,-1,-1};
+	vec f[19];
+	auto ld = [&](const float* p, unsigned xx, bool aligned) -> vec {
+		vec t;
+		if (aligned) { if (NT) t = __builtin_nontemporal_load((const vec*)(p+xx)); else t = *(const vec*)(p+xx); }
+		else __builtin_memcpy(&t, p+xx, sizeof(vec));
+		return t;
+	};
+	auto st = [&](float* p, unsigned xx, bool aligned, vec t) {
+		if (aligned) { if (NTS) __builtin_nontemporal_store(t, (vec*)(p+xx)); else *(vec*)(p+xx) = t; }
+		else __builtin_memcpy(p+xx, &t, sizeof(vec));
+	};
+	f[0] = ld(fi+row0, x, true);
+#pragma unroll
+	for (int k = 0; k < 9; k++) {
+		f[1+2*k] = ld(fi+(size_t)(2+2*k)*N+row0, x, true);
+		if (MODE == 0) f[2+2*k] = ld(fi+(size_t)(1+2*k)*N+row0, x, true);
+		else {
+			const float* p = fi+(size_t)(1+2*k)*N+((size_t)zq[cz[k] == 0 ? 0 : cz[k] > 0 ? 1 : 2]*Ny+yq[cy[k] == 0 ? 0 : cy[k] > 0 ? 1 : 2])*Nx;
+			if (cx[k] == 0) f[2+2*k] = ld(p, x, true);
+			else if (x+V < Nx) f[2+2*k] = ld(p, x+1, false);
+			else { vec t; for (int v = 0; v < V; v++) { unsigned xn = x+v+1; float e = p[xn == Nx ? 0 : xn]; if constexpr (V == 1) t = e; else t[v] = e; } f[2+2*k] = t; }
+		}
+	}
+	vec sum = f[0];
+#pragma unroll
+	for (int i = 1; i < 19; i++) sum += f[i];
+#pragma unroll
+	for (int i = 0; i < 19; i++) f[i] = f[i]*s+sum*1e-3f;
+	st(fi+row0, x, true, f[0]);
+#pragma unroll
+	for (int k = 0; k < 9; k++) {
+		st(fi+(size_t)(2+2*k)*N+row0, x, true, f[2+2*k]);
+		if (MODE == 0) st(fi+(size_t)(1+2*k)*N+row0, x, true, f[1+2*k]);
+		else {
+			float* p = fi+(size_t)(1+2*k)*N+((size_t)zq[cz[k] == 0 ? 0 : cz[k] > 0 ? 1 : 2]*Ny+yq[cy[k] == 0 ? 0 : cy[k] > 0 ? 1 : 2])*Nx;
+			if (cx[k] == 0) st(p, x, true, f[1+2*k]);
+			else if (x+V < Nx) st(p, x+1, false, f[1+2*k]);
+			else { for (int v = 0; v < V; v++) { unsigned xn = x+v+1; float e; if constexpr (V == 1) e = f[1+2*k]; else e = f[1+2*k][v]; p[xn == Nx ? 0 : xn] = e; } }
+		}
+	}
+}
+
+template <class F> float time_ms(F launch, int reps) {
+	hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+	launch(); launch();
+	CHECK(hipEventRecord(a));
+	for (int i = 0; i < reps; i++) launch();
+	CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
+	float ms; CHECK(hipEventElapsedTime(&ms, a, b));
+	return ms/reps;
+}
+template <int V, int MODE, bool NT> void run(float* fi, size_t N, unsigned n, unsigned block, size_t pad, unsigned blocks_per_cu = 0) {
+	const unsigned lanes = n/V, b = block > lanes ? lanes : block, xchunks = (lanes+b-1)/b;
+	const unsigned lds = blocks_per_cu ? (160u*1024u/blocks_per_cu)&~255u : 0u; // dynamic LDS only throttles residency
+	const float ms = time_ms([&]() { hipLaunchKernelGGL((k_rmw<V, MODE, NT>), dim3(xchunks*n*n), dim3(b), lds, 0, fi, N+pad, n, n, n, xchunks, 0.999f); }, 10);
+	printf("rmw19 V=%d mode=%d nt=%d block=%3u pad=%zu blocks/CU<=%u: %.3f ms  %.0f GB/s (%.1f%%)  %.0f MLUPs-equivalent\n", V, MODE, (int)NT, b, pad, blocks_per_cu, ms, 152.0*N/ms/1e6, 152.0*N/ms/1e6/80, N/ms/1e3);
+	fflush(stdout);
+}
+int main(int argc, char** argv) {
+	const unsigned n = argc > 1 ? atoi(argv[1]) : 512;
+	const size_t N = (size_t)n*n*n, padmax = 1u<<20;
+	float* fi; CHECK(hipMalloc(&fi, (N+padmax)*19*sizeof(float)));
+	CHECK(hipMemset(fi, 0, (N+padmax)*19*sizeof(float)));
+	{
+		const size_t n4 = N*19/4/2;
+		const float ms = time_ms([&]() { hipLaunchKernelGGL(k_copy, dim3(256*8), dim3(256), 0, 0, (const float4*)fi, (float4*)fi+n4, n4); }, 10);
+		printf("float4 copy: %.3f ms %.0f GB/s (%.1f%% of 8 TB/s)\n", ms, 2.0*n4*16/ms/1e6, 2.0*n4*16/ms/1e6/80);
+	}
+	{
+		const size_t n4 = N*19/4/2;
+		float4* a = (float4*)fi; float4* b = (float4*)fi+n4;
+		auto rep = [&](const char* name, float ms, double bytes) { printf("%-28s %.3f ms %.0f GB/s (%.1f%% of 8 TB/s)\n", name, ms, bytes/ms/1e6, bytes/ms/1e6/80); fflush(stdout); };
+		rep("copy U=4", time_ms([&]() { hipLaunchKernelGGL((k_copy_u<4, false>), dim3((n4+1023)/1024), dim3(256), 0, 0, a, b, n4); }, 10), 2.0*n4*16);
+		rep("copy U=8", time_ms([&]() { hipLaunchKernelGGL((k_copy_u<8, false>), dim3((n4+2047)/2048), dim3(256), 0, 0, a, b, n4); }, 10), 2.0*n4*16);
+		rep("copy U=8 nt", time_ms([&]() { hipLaunchKernelGGL((k_copy_u<8, true>), dim3((n4+2047)/2048), dim3(256), 0, 0, a, b, n4); }, 10), 2.0*n4*16);
+		rep("copy U=1", time_ms([&]() { hipLaunchKernelGGL((k_copy_u<1, false>), dim3((n4+255)/256), dim3(256), 0, 0, a, b, n4); }, 10), 2.0*n4*16);
+		rep("read U=8", time_ms([&]() { hipLaunchKernelGGL((k_read_u<8>), dim3((2*n4+2047)/2048), dim3(256), 0, 0, a, (float*)b, 2*n4); }, 10), 2.0*n4*16);
+		rep("write U=8", time_ms([&]() { hipLaunchKernelGGL((k_write_u<8>), dim3((2*n4+2047)/2048), dim3(256), 0, 0, a, 2*n4, 0.0f); }, 10), 2.0*n4*16);
+		rep("inplace U=8", time_ms([&]() { hipLaunchKernelGGL((k_inplace_u<8>), dim3((n4+2047)/2048), dim3(256), 0, 0, a, n4, 1.0f); }, 10), 2.0*n4*16);
+		rep("inplace U=2", time_ms([&]() { hipLaunchKernelGGL((k_inplace_u<2>), dim3((n4+511)/512), dim3(256), 0, 0, a, n4, 1.0f); }, 10), 2.0*n4*16);
+		CHECK(hipMemset(fi, 0, (N+padmax)*19*sizeof(float)));
+	}
+	CHECK(hipMemset(fi, 0, (N+padmax)*19*sizeof(float)));
+	struct R { float gbs; char name[96]; };
+	std::vector<R> res;
+	auto sweep = [&](auto kern, int V, int ntl, int nts) {
+		for (unsigned block : {128u, 256u}) for (unsigned k : {0u, 1u, 2u, 3u, 4u, 6u}) for (size_t pad : {(size_t)0, (size_t)4160}) {
+			const unsigned lanes = n/V, b = block > lanes ? lanes : block, xchunks = (lanes+b-1)/b;
+			const unsigned lds = k ? (160u*1024u/k)&~255u : 0u;
+			const float ms = time_ms([&]() { hipLaunchKernelGGL(kern, dim3(xchunks*n*n), dim3(b), lds, 0, fi, N+pad, n, n, n, xchunks, 0.999f); }, 6);
+			R r; r.gbs = 152.0*N/ms/1e6;
+			snprintf(r.name, sizeof(r.name), "V=%d ntload=%d ntstore=%d block=%u blocks/CU<=%u pad=%zu", V, ntl, nts, b, k, pad);
+			res.push_back(r);
+		}
+	};
+	sweep(k_rmw<1, 1, false, false>, 1, 0, 0); sweep(k_rmw<1, 1, true, false>, 1, 1, 0); sweep(k_rmw<1, 1, false, true>, 1, 0, 1); sweep(k_rmw<1, 1, true, true>, 1, 1, 1);
+	sweep(k_rmw<2, 1, false, false>, 2, 0, 0); sweep(k_rmw<2, 1, true, false>, 2, 1, 0); sweep(k_rmw<2, 1, false, true>, 2, 0, 1); sweep(k_rmw<2, 1, true, true>, 2, 1, 1);
+	sweep(k_rmw<4, 1, false, false>, 4, 0, 0); sweep(k_rmw<4, 1, true, false>, 4, 1, 0); sweep(k_rmw<4, 1, false, true>, 4, 0, 1); sweep(k_rmw<4, 1, true, true>, 4, 1, 1);
+	std::sort(res.begin(), res.end(), [](const R& a, const R& b) { return a.gbs > b.gbs; });
+	for (size_t i = 0; i < res.size(); i++) printf("%5.0f GB/s (%.1f%%)  %s\n", res[i].gbs, res[i].gbs/80, res[i].name);
+	return 0;
+}
