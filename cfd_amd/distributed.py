@@ -1,0 +1,285 @@
+"""One process per GPU: z-slab decomposition with the per-step DDF halo exchange over torch.distributed.
+
+This is the multi-process counterpart of LBM::communicate_field (FluidX3D-master/src/lbm.cpp:2120-2182): the
+reference swaps host pointers between domains that live in one process; here every rank owns one slab
+(Dx=Dy=1, Dz=world) and sends its two face buffers to its z-neighbours (RCCL send/recv over xGMI when the
+backend is "nccl", which is RCCL on ROCm).  There is no collective on the data path, only point-to-point
+exchanges with at most two peers per rank; the periodic wrap connects the last rank with rank 0.
+
+Per time step (overlapped order):
+  1. stream_collide on the two lattice planes next to the halos           (compute stream)
+  2. pack -> send/recv -> unpack                                          (communication stream)
+  3. stream_collide on all other planes, concurrently with 2              (compute stream)
+  4. the compute stream waits for 2
+Every DDF slot is read and written by exactly one cell per step, and the slots that pack reads / unpack writes
+belong to cells of the two boundary planes (pack) or are only read by them in the NEXT step (unpack), so 2 and 3
+never touch the same memory.
+
+The slab engine is abstract (SlabOps) so that the exchange logic can be driven by CPU tensors in tests; the
+product implementation is HipSlabOps (HIP kernels through the C ABI, staging buffers owned by torch).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import decomposition
+from . import lbm as L
+
+WHAT = {"fi": L.HALO_FI, "rho_u_flags": L.HALO_RHO_U_FLAGS, "flags": L.HALO_FLAGS, "F": L.HALO_F}
+
+
+class SlabOps:
+    """What DistributedLBM needs from the engine that owns this rank's slab."""
+    local = (0, 0, 0)          # local lattice size including the two z halo planes
+    buffers = None             # dict send_p, send_m, recv_p, recv_m -> 1-D uint8 torch tensors
+    def upload(self, rho, u, flags, F): raise NotImplementedError
+    def download(self, names): raise NotImplementedError
+    def initialize(self): raise NotImplementedError
+    def collide_planes(self, t, f, z0, z1): raise NotImplementedError
+    def update_fields(self, t, f): raise NotImplementedError
+    def update_force_field(self, t): raise NotImplementedError
+    def pack(self, what, t): raise NotImplementedError
+    def unpack(self, what, t): raise NotImplementedError
+    def halo_bytes(self, what): raise NotImplementedError
+    def fork(self): pass       # communication stream waits for the compute stream and becomes current
+    def end_fork(self): pass   # back to the compute stream
+    def join(self): pass       # compute stream waits for the communication stream
+    def sync(self): pass
+
+
+class HipSlabOps(SlabOps):
+    """The slab lives in an lbmhip domain on this rank's GPU; torch owns the staging buffers and the streams."""
+
+    def __init__(self, local, world, Q, storage, collision, features, nu, offset_z, device):
+        lib = L.lib()
+        self.lib = lib
+        self.device = torch.device("cuda", device)
+        mask = L.feature_mask(features)
+        cfg = L.Config(local[0], local[1], local[2], 1, 1, world, 0, 0, offset_z, Q, L.STORAGE[storage], L.COLLISION[collision], mask, float(nu), device)
+        self.dom = L.Domain(cfg)
+        self.local = tuple(local)
+        self.has_F = bool(mask & L.FEATURES["FORCE_FIELD"])
+        self.compute = torch.cuda.Stream(device=self.device)
+        self.comm = torch.cuda.Stream(device=self.device)
+        L.check(lib.lbmhip_set_stream(self.dom.h, C.c_void_p(self.compute.cuda_stream)))
+        self.buffers = None
+        if world > 1:
+            cap = local[0] * local[1] * max(decomposition.halo_bytes_per_cell("fi", Q, 4 if storage == "FP32" else 2), 17)
+            self.buffers = {k: torch.empty(cap, dtype=torch.uint8, device=self.device) for k in ("send_p", "send_m", "recv_p", "recv_m")}
+            b = self.buffers
+            L.check(lib.lbmhip_halo_set_buffers(self.dom.h, C.c_void_p(b["send_p"].data_ptr()), C.c_void_p(b["send_m"].data_ptr()),
+                                                C.c_void_p(b["recv_p"].data_ptr()), C.c_void_p(b["recv_m"].data_ptr()), C.c_uint64(cap)))
+        self._stream_ctx = None
+
+    def close(self):
+        self.dom.close()
+
+    def upload(self, rho, u, flags, F):
+        d = self.dom
+        d.rho[...] = rho.ravel(); d.u[...] = u.ravel(); d.flags[...] = flags.ravel()
+        d.upload(L.FIELD_RHO, d.rho); d.upload(L.FIELD_U, d.u); d.upload(L.FIELD_FLAGS, d.flags)
+        if self.has_F:
+            d.F[...] = F.ravel(); d.upload(L.FIELD_F, d.F)
+
+    def download(self, names):
+        d = self.dom
+        out = {}
+        for name in names:
+            if name == "rho": d.download(L.FIELD_RHO, d.rho); out[name] = d.rho
+            elif name == "u": d.download(L.FIELD_U, d.u); out[name] = d.u
+            elif name == "flags": d.download(L.FIELD_FLAGS, d.flags); out[name] = d.flags
+            elif name == "F" and self.has_F: d.download(L.FIELD_F, d.F); out[name] = d.F
+            elif name == "fi": out[name] = d.download_fi()
+        return out
+
+    def initialize(self):
+        L.check(self.lib.lbmhip_initialize(self.dom.h))
+
+    def collide_planes(self, t, f, z0, z1):
+        L.check(self.lib.lbmhip_stream_collide_planes(self.dom.h, C.c_uint64(t), C.c_float(f[0]), C.c_float(f[1]), C.c_float(f[2]), int(z0), int(z1)))
+
+    def update_fields(self, t, f):
+        L.check(self.lib.lbmhip_update_fields(self.dom.h, C.c_uint64(t), C.c_float(f[0]), C.c_float(f[1]), C.c_float(f[2])))
+
+    def update_force_field(self, t):
+        L.check(self.lib.lbmhip_update_force_field(self.dom.h, C.c_uint64(t)))
+
+    def pack(self, what, t):
+        L.check(self.lib.lbmhip_halo_pack(self.dom.h, WHAT[what], 2, C.c_uint64(t)))
+
+    def unpack(self, what, t):
+        L.check(self.lib.lbmhip_halo_unpack(self.dom.h, WHAT[what], 2, C.c_uint64(t)))
+
+    def halo_bytes(self, what):
+        n = C.c_uint64()
+        L.check(self.lib.lbmhip_halo_bytes(self.dom.h, WHAT[what], 2, C.byref(n)))
+        return n.value
+
+    def fork(self):
+        self.comm.wait_stream(self.compute)
+        self._stream_ctx = torch.cuda.stream(self.comm)
+        self._stream_ctx.__enter__()
+        L.check(self.lib.lbmhip_set_stream(self.dom.h, C.c_void_p(self.comm.cuda_stream)))
+
+    def end_fork(self):
+        L.check(self.lib.lbmhip_set_stream(self.dom.h, C.c_void_p(self.compute.cuda_stream)))
+        self._stream_ctx.__exit__(None, None, None)
+        self._stream_ctx = None
+
+    def join(self):
+        self.compute.wait_stream(self.comm)
+
+    def sync(self):
+        self.compute.synchronize()
+        self.comm.synchronize()
+
+
+class DistributedLBM:
+    """This rank's slab of a global Nx x Ny x Nz lattice split into `world` z-slabs.
+
+    Host fields rho/u/flags(/F) cover the rank's own planes only ([z_local, y, x]; `origin` is their global offset),
+    so setups written against N/origin/rho.shape fill them without materialising the global lattice.
+    """
+
+    def __init__(self, N, nu, Q=19, storage="FP32", collision="SRT", features=(), f=(0.0, 0.0, 0.0), rank=None, world=None, ops_factory=None, overlap=True, group=None):
+        self.group = group
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world = dist.get_world_size(group) if world is None else world
+        D = (1, 1, self.world)
+        self.N = decomposition.rounded_size(N, D)
+        self.D, self.Q, self.storage, self.collision, self.features, self.nu = D, Q, storage, collision, tuple(features), float(nu)
+        self.f = tuple(float(v) for v in f)
+        self.local = decomposition.local_size(self.N, D)
+        self.nz = self.N[2] // self.world
+        self.origin = (0, 0, self.rank * self.nz)
+        self.hz = 1 if self.world > 1 else 0
+        if ops_factory is None:
+            dev = torch.cuda.current_device()
+            ops_factory = lambda: HipSlabOps(self.local, self.world, Q, storage, collision, features, nu, self.origin[2] - self.hz, dev)
+        self.ops = ops_factory()
+        Nx, Ny, _ = self.N
+        self.rho = np.ones((self.nz, Ny, Nx), dtype=np.float32)
+        self.u = np.zeros((3, self.nz, Ny, Nx), dtype=np.float32)
+        self.flags = np.zeros((self.nz, Ny, Nx), dtype=np.uint8)
+        self.has_F = "FORCE_FIELD" in features
+        self.F = np.zeros((3, self.nz, Ny, Nx), dtype=np.float32) if self.has_F else None
+        self.update_fields_ext = "UPDATE_FIELDS" in features
+        self.t = 0
+        self.initialized = False
+        self.t_last_update_fields = None
+        self.overlap = bool(overlap) and self.world > 1 and self.local[2] >= 5
+        self.next = (self.rank + 1) % self.world
+        self.prev = (self.rank - 1) % self.world
+        self._host_staging = None
+
+    def get_N(self):
+        return self.N[0] * self.N[1] * self.N[2]
+
+    def close(self):
+        if hasattr(self.ops, "close"):
+            self.ops.close()
+
+    # ---- the exchange: + face to the next rank's - halo, - face to the previous rank's + halo (lbm.cpp:2162-2181)
+    def _exchange(self, nbytes):
+        b = self.ops.buffers
+        backend = dist.get_backend(self.group)
+        views = {k: v[:nbytes] for k, v in b.items()}
+        on_device = views["send_p"].is_cuda
+        if on_device and backend != "nccl":  # rehearsal path (gloo): stage through host memory
+            if self._host_staging is None or self._host_staging["send_p"].numel() < nbytes:
+                self._host_staging = {k: torch.empty(b[k].numel(), dtype=torch.uint8).pin_memory() for k in b}
+            h = {k: v[:nbytes] for k, v in self._host_staging.items()}
+            h["send_p"].copy_(views["send_p"]); h["send_m"].copy_(views["send_m"])
+            torch.cuda.current_stream().synchronize()
+            self._p2p(h)
+            views["recv_p"].copy_(h["recv_p"]); views["recv_m"].copy_(h["recv_m"])
+        else:
+            self._p2p(views)
+
+    def _p2p(self, v):
+        g = self.group
+        gr = (lambda r: dist.get_global_rank(g, r)) if g is not None else (lambda r: r)
+        ops = [dist.P2POp(dist.isend, v["send_p"], gr(self.next), g, tag=0), dist.P2POp(dist.isend, v["send_m"], gr(self.prev), g, tag=1),
+               dist.P2POp(dist.irecv, v["recv_m"], gr(self.prev), g, tag=0), dist.P2POp(dist.irecv, v["recv_p"], gr(self.next), g, tag=1)]
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+
+    def _communicate(self, what):
+        if self.world <= 1:
+            return
+        self.ops.pack(what, self.t)
+        self._exchange(self.ops.halo_bytes(what))
+        self.ops.unpack(what, self.t)
+
+    # ---- LBM::initialize (lbm.cpp:1354-1409)
+    def initialize(self):
+        Lx, Ly, Lz = self.local
+        hz = self.hz
+        rho = np.ones((Lz, Ly, Lx), dtype=np.float32); rho[hz:Lz - hz] = self.rho
+        u = np.zeros((3, Lz, Ly, Lx), dtype=np.float32); u[:, hz:Lz - hz] = self.u
+        flags = np.zeros((Lz, Ly, Lx), dtype=np.uint8); flags[hz:Lz - hz] = self.flags
+        F = None
+        if self.has_F:
+            F = np.zeros((3, Lz, Ly, Lx), dtype=np.float32); F[:, hz:Lz - hz] = self.F
+        self.ops.upload(rho, u, flags, F)
+        if self.has_F:
+            self._communicate("F")
+        self.t = 1
+        self._communicate("rho_u_flags")
+        self.ops.initialize()
+        self._communicate("rho_u_flags")
+        self._communicate("fi")
+        self.ops.sync()
+        self.t = 0
+        self.initialized = True
+        self.t_last_update_fields = 0 if self.update_fields_ext else None
+
+    # ---- LBM::do_time_step (lbm.cpp:1411-1459)
+    def do_time_step(self):
+        Lz = self.local[2]
+        o = self.ops
+        if self.world <= 1:
+            o.collide_planes(self.t, self.f, 0, Lz)
+        elif self.overlap:
+            o.collide_planes(self.t, self.f, 1, 2)
+            o.collide_planes(self.t, self.f, Lz - 2, Lz - 1)
+            o.fork()
+            try:
+                self._communicate("fi")
+            finally:
+                o.end_fork()
+            o.collide_planes(self.t, self.f, 2, Lz - 2)
+            o.join()
+        else:
+            o.collide_planes(self.t, self.f, 0, Lz)
+            self._communicate("fi")
+        self.t += 1
+        if self.update_fields_ext:
+            self.t_last_update_fields = self.t
+
+    def run(self, steps):
+        if not self.initialized:
+            self.initialize()
+        for _ in range(int(steps)):
+            self.do_time_step()
+        self.ops.sync()
+
+    def update_fields(self):
+        if not self.update_fields_ext and self.t != self.t_last_update_fields:
+            self.ops.update_fields(self.t, self.f)
+            self.t_last_update_fields = self.t
+        self.ops.sync()
+
+    def read_from_device(self):
+        if self.initialized:
+            self.update_fields()
+        Lx, Ly, Lz = self.local
+        hz = self.hz
+        got = self.ops.download(("rho", "u", "flags") + (("F",) if self.has_F else ()))
+        self.rho[...] = got["rho"].reshape(Lz, Ly, Lx)[hz:Lz - hz]
+        self.u[...] = got["u"].reshape(3, Lz, Ly, Lx)[:, hz:Lz - hz]
+        self.flags[...] = got["flags"].reshape(Lz, Ly, Lx)[hz:Lz - hz]
+        if self.has_F:
+            self.F[...] = got["F"].reshape(3, Lz, Ly, Lx)[:, hz:Lz - hz]

@@ -9,6 +9,8 @@ import os
 
 import numpy as np
 
+from . import decomposition
+
 STORAGE = {"FP32": 0, "FP16S": 1, "FP16C": 2}
 COLLISION = {"SRT": 0, "TRT": 1}
 FEATURES = {"UPDATE_FIELDS": 1, "VOLUME_FORCE": 2, "MOVING_BOUNDARIES": 4, "EQUILIBRIUM_BOUNDARIES": 8,
@@ -117,14 +119,14 @@ class LBM:
         D = tuple(int(v) for v in D)
         if D[0] * D[1] * D[2] == 0:
             raise LbmHipError("You specified 0 LBM grid domains (%dx%dx%d)." % D)
-        self.N = tuple((int(N[k]) // D[k]) * D[k] for k in range(3))  # lbm.cpp:1043-1054
+        self.N = decomposition.rounded_size(N, D)  # lbm.cpp:1043-1054
         self.D, self.Q, self.storage, self.collision, self.features, self.nu = D, Q, storage, collision, tuple(features), float(nu)
         self.fx, self.fy, self.fz = (float(v) for v in f)
         mask = feature_mask(features)
         if not (mask & FEATURES["VOLUME_FORCE"]) and (self.fx != 0.0 or self.fy != 0.0 or self.fz != 0.0):
             raise LbmHipError("Volume force is set in LBM constructor, but VOLUME_FORCE is not enabled.")  # lbm.cpp:1211-1215
-        self.H = tuple(1 if d > 1 else 0 for d in D)
-        self.local = tuple(self.N[k] // D[k] + 2 * self.H[k] for k in range(3))
+        self.H = decomposition.halo(D)
+        self.local = decomposition.local_size(self.N, D)
         nd = D[0] * D[1] * D[2]
         if devices is None:
             have = device_count()
@@ -132,9 +134,8 @@ class LBM:
         self.domains = []
         try:
             for d in range(nd):
-                x, y, z = (d % (D[0] * D[1])) % D[0], (d % (D[0] * D[1])) // D[0], d // (D[0] * D[1])
-                cfg = Config(self.local[0], self.local[1], self.local[2], D[0], D[1], D[2],
-                             x * self.N[0] // D[0] - self.H[0], y * self.N[1] // D[1] - self.H[1], z * self.N[2] // D[2] - self.H[2],
+                off = decomposition.domain_offset(d, self.N, D)
+                cfg = Config(self.local[0], self.local[1], self.local[2], D[0], D[1], D[2], off[0], off[1], off[2],
                              Q, STORAGE[storage], COLLISION[collision], mask, self.nu, devices[d])
                 self.domains.append(Domain(cfg))
         except Exception:
@@ -199,12 +200,7 @@ class LBM:
 
     # ---- global <-> per-domain mapping (Memory_Container::reference, lbm.hpp:265-288)
     def _slices(self, d):
-        Dx, Dy, Dz = self.D
-        dx, dy, dz = (d % (Dx * Dy)) % Dx, (d % (Dx * Dy)) // Dx, d // (Dx * Dy)
-        n = tuple(self.N[k] // self.D[k] for k in range(3))
-        glob = (slice(dz * n[2], (dz + 1) * n[2]), slice(dy * n[1], (dy + 1) * n[1]), slice(dx * n[0], (dx + 1) * n[0]))
-        loc = (slice(self.H[2], self.H[2] + n[2]), slice(self.H[1], self.H[1] + n[1]), slice(self.H[0], self.H[0] + n[0]))
-        return glob, loc
+        return decomposition.slices(d, self.N, self.D)
 
     def _view(self, a, comps):
         Lx, Ly, Lz = self.local

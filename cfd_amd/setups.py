@@ -9,9 +9,16 @@ import numpy as np
 TYPE_S, TYPE_E, TYPE_X, TYPE_Y = 0x01, 0x02, 0x40, 0x80
 
 
+def _axes(lbm):
+    """Global x, y, z coordinates of the cells held by `lbm` (its fields may cover only a slab of the lattice)."""
+    nz, ny, nx = lbm.rho.shape
+    ox, oy, oz = getattr(lbm, "origin", (0, 0, 0))
+    return np.arange(ox, ox + nx), np.arange(oy, oy + ny), np.arange(oz, oz + nz)
+
+
 def _grid(lbm):
-    Nx, Ny, Nz = lbm.N
-    z, y, x = np.meshgrid(np.arange(Nz), np.arange(Ny), np.arange(Nx), indexing="ij")
+    xa, ya, za = _axes(lbm)
+    z, y, x = np.meshgrid(za, ya, xa, indexing="ij")
     return x, y, z
 
 
@@ -21,21 +28,27 @@ def nu_from_Re(Re, x, u):
 
 
 def taylor_green(lbm, A=0.25, periodicity=1):
-    """3D Taylor-Green vortices, fully periodic (setup.cpp.bak:40-59)."""
+    """3D Taylor-Green vortices, fully periodic (setup.cpp.bak:40-59).  Every factor depends on one coordinate only,
+    so the field is built from 1-D float32 factors multiplied in the order the reference writes them."""
     Nx, Ny, Nz = lbm.N
-    x, y, z = _grid(lbm)
+    xa, ya, za = _axes(lbm)
     f32 = np.float32
     a, b, c = f32(Nx) / f32(periodicity), f32(Ny) / f32(periodicity), f32(Nz) / f32(periodicity)
-    fx = x.astype(f32) + f32(0.5) - f32(0.5) * f32(Nx)
-    fy = y.astype(f32) + f32(0.5) - f32(0.5) * f32(Ny)
-    fz = z.astype(f32) + f32(0.5) - f32(0.5) * f32(Nz)
+    fx = xa.astype(f32) + f32(0.5) - f32(0.5) * f32(Nx)
+    fy = ya.astype(f32) + f32(0.5) - f32(0.5) * f32(Ny)
+    fz = za.astype(f32) + f32(0.5) - f32(0.5) * f32(Nz)
     pif = f32(3.1415927)
     A = f32(A)
     ax, ay, az = f32(2.0) * pif * fx / a, f32(2.0) * pif * fy / b, f32(2.0) * pif * fz / c
-    lbm.u[0] = A * np.cos(ax) * np.sin(ay) * np.sin(az)
-    lbm.u[1] = -A * np.sin(ax) * np.cos(ay) * np.sin(az)
-    lbm.u[2] = A * np.sin(ax) * np.sin(ay) * np.cos(az)
-    lbm.rho[...] = f32(1.0) - A * A * f32(3.0) / f32(4.0) * (np.cos(f32(4.0) * pif * fx / a) + np.cos(f32(4.0) * pif * fy / b))
+    cx, sx = np.cos(ax)[None, None, :], np.sin(ax)[None, None, :]
+    cy, sy = np.cos(ay)[None, :, None], np.sin(ay)[None, :, None]
+    cz, sz = np.cos(az)[:, None, None], np.sin(az)[:, None, None]
+    lbm.u[0] = ((A * cx) * sy) * sz
+    lbm.u[1] = ((-A * sx) * cy) * sz
+    lbm.u[2] = ((A * sx) * sy) * cz
+    c4x = np.cos(f32(4.0) * pif * fx / a)[None, None, :]
+    c4y = np.cos(f32(4.0) * pif * fy / b)[None, :, None]
+    lbm.rho[...] = f32(1.0) - A * A * f32(3.0) / f32(4.0) * (c4x + c4y) + f32(0.0) * sz
     lbm.flags[...] = 0
 
 

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Builds every oracle/_ref library the tests and the benchmark use (test infrastructure; needs /root/reference).
+
+One library per configuration because the reference bakes lattice size, velocity set and extensions into the
+kernel text (FluidX3D-master/src/lbm.cpp:424-665).  Configurations: every parity case of tests/cases.py plus the
+CPU-baseline lattice of bench.py."""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.normpath(os.path.join(HERE, "..", ".."))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import build_ref  # noqa: E402
+from cfd_amd import decomposition  # noqa: E402
+
+
+def case_config(tag, kw):
+    D = tuple(kw.get("D", (1, 1, 1)))
+    N = decomposition.rounded_size(kw["N"], D)
+    return {"tag": tag, "N": decomposition.local_size(N, D), "D": D, "O": decomposition.domain_offset(0, N, D), "Q": kw.get("Q", 19),
+            "storage": kw.get("storage", "FP32"), "collision": kw.get("collision", "SRT"), "nu": kw["nu"], "features": list(kw.get("features", ()))}
+
+
+def all_configs():
+    from tests.cases import CASES
+    cfgs = [case_config(name, c["kw"]) for name, c in sorted(CASES.items())]
+    cfgs.append(case_config("bench_tgv256", dict(N=(256, 256, 256), nu=0.01)))
+    cfgs.append(case_config("cavity128", dict(N=(128, 128, 128), nu=0.0126, features=("MOVING_BOUNDARIES",))))
+    return cfgs
+
+
+if __name__ == "__main__":
+    if not build_ref.available():
+        print("reference sources or clang missing: nothing built")
+        sys.exit(0)
+    for path in build_ref.build_all(all_configs(), force="--force" in sys.argv):
+        print(path)

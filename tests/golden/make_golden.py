@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/<case>.npz from the reference's own kernels compiled for the host (oracle/_ref).
+
+Run in the build container (needs /root/reference through oracle/ref/ref_variants.py):
+    make -C oracle && python tests/golden/make_golden.py
+Each fixture holds, for one parity case of tests/cases.py after its `steps` time steps:
+  crc_*      CRC-32 of the raw bytes of flags, rho, u, (F,) and of every domain's DDF buffer (bit-exact pins),
+  sum_*      float64 sums of rho and |u| (size-independent sanity),
+  flags      the complete flag lattice (uint8),
+  rho_sub, u_sub   every 2nd cell per axis of rho and u (for tolerance-based comparison of the 16-bit formats),
+plus the generating configuration.  Only data is stored; no reference source.
+"""
+import json
+import os
+import sys
+import zlib
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from oracle import harness as H  # noqa: E402
+from tests.cases import CASES  # noqa: E402
+
+
+def crc(a):
+    return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
+
+
+def summarize(lbm):
+    """The pins of one finished run (works for OracleLBM and cfd_amd.LBM alike)."""
+    out = {"crc_flags": crc(lbm.flags), "crc_rho": crc(lbm.rho), "crc_u": crc(lbm.u),
+           "sum_rho": float(lbm.rho.sum(dtype=np.float64)), "sum_absu": float(np.abs(lbm.u).sum(dtype=np.float64))}
+    if lbm.F is not None:
+        out["crc_F"] = crc(lbm.F)
+    return out
+
+
+def main():
+    out_dir = os.path.dirname(os.path.abspath(__file__))
+    for name, case in sorted(CASES.items()):
+        kw = dict(case["kw"])
+        ref = H.OracleLBM(engine_factory=lambda local, D, n=name: H.RefEngine(n), **kw)
+        case["setup"](ref)
+        ref.run(case["steps"])
+        ref.read_from_device()
+        if ref.F is not None:
+            ref.update_force_field()
+            ref.read_from_device()
+        pins = summarize(ref)
+        pins["crc_fi"] = [crc(d.fi) for d in ref.domains]
+        meta = {"case": name, "steps": case["steps"], "kw": {k: (list(v) if isinstance(v, tuple) else v) for k, v in kw.items()},
+                "generator": "oracle/_ref (reference OpenCL kernels, clang -x cl, x86-64), tests/golden/make_golden.py"}
+        np.savez_compressed(os.path.join(out_dir, name + ".npz"), meta=json.dumps(meta), pins=json.dumps(pins), flags=ref.flags,
+                            rho_sub=ref.rho[::2, ::2, ::2], u_sub=ref.u[:, ::2, ::2, ::2])
+        print(name, pins["crc_rho"], pins["crc_u"], "%.6f" % pins["sum_rho"])
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,67 @@
+"""Test-only SlabOps over the CPU oracle, so the torch.distributed exchange logic of cfd_amd.distributed can run
+on CPU ranks (gloo).  The product never imports this."""
+import numpy as np
+import torch
+
+from cfd_amd.distributed import SlabOps
+from oracle import harness as H
+
+
+class OracleSlabOps(SlabOps):
+    def __init__(self, local, world, Q, storage, collision, features, nu):
+        self.local = tuple(local)
+        self.engine = H.PortEngine(local, (1, 1, world), Q, storage, collision, features, nu)
+        n = local[0] * local[1] * local[2]
+        self.n, self.Q, self.storage = n, Q, storage
+        self.fi = np.zeros(Q * n, dtype=np.float32 if storage == "FP32" else np.uint16)
+        self.rho = np.ones(n, dtype=np.float32)
+        self.u = np.zeros(3 * n, dtype=np.float32)
+        self.flags = np.zeros(n, dtype=np.uint8)
+        self.F = np.zeros(3 * n, dtype=np.float32) if "FORCE_FIELD" in features else None
+        self.per_cell = {"fi": H.TRANSFERS[Q] * (4 if storage == "FP32" else 2), "rho_u_flags": 17, "flags": 1, "F": 12}
+        cap = local[0] * local[1] * max(self.per_cell["fi"], 17)
+        self.np_buffers = {k: np.zeros(cap, dtype=np.uint8) for k in ("send_p", "send_m", "recv_p", "recv_m")}
+        self.buffers = {k: torch.from_numpy(v) for k, v in self.np_buffers.items()} if world > 1 else None
+        self.cfg = self.engine.cfg
+
+    def upload(self, rho, u, flags, F):
+        self.rho[...] = rho.ravel(); self.u[...] = u.ravel(); self.flags[...] = flags.ravel()
+        if self.F is not None:
+            self.F[...] = F.ravel()
+
+    def download(self, names):
+        return {k: getattr(self, k) for k in names}
+
+    def initialize(self):
+        self.engine.initialize(self.fi, self.rho, self.u, self.flags)
+
+    def collide_planes(self, t, f, z0, z1):
+        # the oracle works on whole lattices: restrict it by masking the other planes as solid for this call
+        Lx, Ly, Lz = self.local
+        hz = 1 if self.cfg.Dz > 1 else 0
+        z0, z1 = max(z0, hz), min(z1, Lz - hz)
+        if z0 >= z1:
+            return
+        saved = self.flags.copy()
+        fl = self.flags.reshape(Lz, Ly, Lx)
+        fl[:z0] = 1; fl[z1:] = 1
+        # neighbour flags matter to moving boundaries only; those cases run the un-split path in the tests
+        self.engine.stream_collide(self.fi, self.rho, self.u, self.flags, t, f[0], f[1], f[2], self.F)
+        self.flags[...] = saved
+
+    def update_fields(self, t, f):
+        self.engine.update_fields(self.fi, self.rho, self.u, self.flags, t, f[0], f[1], f[2], self.F)
+
+    def update_force_field(self, t):
+        self.engine.update_force_field(self.fi, self.flags, t, self.F)
+
+    def _transfer(self, what, t, insert):
+        p = self.np_buffers["recv_p" if insert else "send_p"]
+        m = self.np_buffers["recv_m" if insert else "send_m"]
+        if what == "fi": self.engine.transfer_fi(insert, 2, t, p, m, self.fi)
+        elif what == "rho_u_flags": self.engine.transfer_rho_u_flags(insert, 2, t, p, m, self.rho, self.u, self.flags)
+        elif what == "F": self.engine.transfer_F(insert, 2, t, p, m, self.F)
+
+    def pack(self, what, t): self._transfer(what, t, 0)
+    def unpack(self, what, t): self._transfer(what, t, 1)
+    def halo_bytes(self, what): return self.local[0] * self.local[1] * self.per_cell[what]
