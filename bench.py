@@ -40,7 +40,7 @@ def cpu_baseline(threads):
     setups.taylor_green(lbm)
     lbm.initialize()
     t0 = time.time(); lbm.run(1, threads=cores); first = time.time() - t0
-    steps = int(max(2, min(60, 12.0 / max(first, 1e-3))))
+    steps = int(max(2, min(400, 15.0 / max(first, 1e-3))))
     t0 = time.time(); lbm.run(steps, threads=cores); dt = time.time() - t0
     return {"value": round(n ** 3 * steps / dt / 1e6, 2), "unit": "MLUPs/s", "cores": cores, "kind": kind,
             "sample": "taylor_green %d^3 D3Q19 SRT FP32, %d steps in %.1f s" % (n, steps, dt)}
@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--storage", default="FP32", choices=["FP32", "FP16S", "FP16C"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse several ranks on one GPU)")
     a = ap.parse_args()
 
     import torch
@@ -79,9 +80,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d; launch N>1 through torch.distributed.run" % (a.gpus, world))
-    torch.cuda.set_device(local_rank)
+    device = local_rank % torch.cuda.device_count()  # ranks share a GPU only in a gloo rehearsal
+    torch.cuda.set_device(device)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(a.backend)
 
     n = a.size
     lbm = DistributedLBM((n, n, n * world), 0.01, Q=19, storage=a.storage, collision="SRT", rank=rank, world=world, overlap=not a.no_overlap)

@@ -44,8 +44,8 @@ template <int Q, int ST, int COLL, int FEAT, int V, bool FIELDS_ONLY>
 __global__ __launch_bounds__(256) void k_collide(const Args a) {
 	using S = Store<ST>;
 	using raw = typename S::raw;
-	const uint32_t chunk = blockIdx.x%a.xchunks, r = blockIdx.x/a.xchunks;
-	const uint32_t z = a.z0+r/a.Ny, y = r%a.Ny;
+	// grid = (xchunks*Ny, planes): a launch may not exceed 2^32 work-items per grid dimension, and 1600^3 lattices do
+	const uint32_t chunk = blockIdx.x%a.xchunks, y = blockIdx.x/a.xchunks, z = a.z0+blockIdx.y;
 	if (a.hy && (y == 0u || y == a.Ny-1u)) return;
 	const uint32_t x = (chunk*blockDim.x+threadIdx.x)*V;
 	if (x >= a.Nx) return;
@@ -191,13 +191,13 @@ __global__ __launch_bounds__(256) void k_collide(const Args a) {
 #ifdef LBM_SMALL_KERNELS // the one-cell-per-thread kernels are compiled once, in lbmhip.hip
 // ---------------------------------------------------------------------------------------------- one-cell-per-thread helpers
 struct Cell { uint32_t x, y, z; uint64_t n; bool valid; };
-__device__ __forceinline__ Cell cell_of_thread(const Args& a) {
+__device__ __forceinline__ Cell cell_of_thread(const Args& a) { // grid = (ceil(Nx*Ny/block), Nz): one lattice plane per blockIdx.y
 	Cell c;
-	const uint64_t n = (uint64_t)blockIdx.x*blockDim.x+threadIdx.x;
-	c.n = n; c.valid = n < a.N;
-	const uint64_t plane = (uint64_t)a.Nx*a.Ny;
-	const uint32_t t = (uint32_t)(n%plane);
-	c.x = t%a.Nx; c.y = t/a.Nx; c.z = (uint32_t)(n/plane);
+	const uint64_t plane = (uint64_t)a.Nx*a.Ny, t = (uint64_t)blockIdx.x*blockDim.x+threadIdx.x;
+	c.valid = t < plane;
+	c.z = blockIdx.y;
+	c.x = (uint32_t)(t%a.Nx); c.y = (uint32_t)(t/a.Nx);
+	c.n = (uint64_t)c.z*plane+t;
 	return c;
 }
 __device__ __forceinline__ bool is_halo(const Args& a, const Cell& c) { // kernel.cpp:850-853
@@ -270,8 +270,9 @@ template <int Q, int ST> __global__ __launch_bounds__(256) void k_update_force_f
 }
 // FluidX3D-master/src/kernel.cpp:1911-1917 (runs on the halo too)
 __global__ __launch_bounds__(256) void k_reset_force_field(const Args a) {
-	const uint64_t n = (uint64_t)blockIdx.x*blockDim.x+threadIdx.x;
-	if (n >= a.N) return;
+	const Cell c = cell_of_thread(a);
+	if (!c.valid) return;
+	const uint64_t n = c.n;
 	a.F[n] = 0.0f; a.F[a.N+n] = 0.0f; a.F[2ull*a.N+n] = 0.0f;
 }
 // FluidX3D-master/src/kernel.cpp:1449-1465

@@ -40,6 +40,23 @@ struct lbmhip_domain {
 	float w;
 };
 
+// 64-bit safe fill (fields of the largest lattices exceed what 32-bit element counts can address)
+__global__ __launch_bounds__(256) void k_fill_u32(uint32_t* p, uint32_t value, uint64_t count) {
+	for (uint64_t i = (uint64_t)blockIdx.x*blockDim.x+threadIdx.x; i < count; i += (uint64_t)gridDim.x*blockDim.x) p[i] = value;
+}
+static hipError_t fill_bytes(void* p, uint8_t byte, uint64_t bytes, hipStream_t stream) { // p is 256-byte aligned (hipMalloc)
+	const uint32_t v = 0x01010101u*byte;
+	const uint64_t words = bytes/4u;
+	if (words) hipLaunchKernelGGL(k_fill_u32, dim3(4096), dim3(256), 0, stream, (uint32_t*)p, v, words);
+	hipError_t e = hipGetLastError();
+	if (e == hipSuccess && bytes%4u) e = hipMemsetAsync((char*)p+words*4u, byte, bytes%4u, stream);
+	return e;
+}
+static hipError_t fill_words(void* p, uint32_t word, uint64_t count, hipStream_t stream) {
+	if (count) hipLaunchKernelGGL(k_fill_u32, dim3(4096), dim3(256), 0, stream, (uint32_t*)p, word, count);
+	return hipGetLastError();
+}
+
 static uint32_t q_transfers(uint32_t Q) { return Q == 9u ? 3u : Q == 27u ? 9u : 5u; }
 static uint32_t storage_bytes(uint32_t st) { return st == LBMHIP_FP32 ? 4u : 2u; }
 static bool valid_q(uint32_t Q) { return Q == 9u || Q == 15u || Q == 19u || Q == 27u; }
@@ -118,6 +135,7 @@ int lbmhip_domain_create(const lbmhip_config* c, lbmhip_domain** out) {
 	NEED(c->collision <= LBMHIP_TRT, "No LBM collision operator selected (collision=%u).", c->collision);
 	NEED(c->nu > 0.0f, c->nu == 0.0f ? "Viscosity cannot be 0." : "Viscosity cannot be negative.");
 	NEED((c->features&~63u) == 0u, "unknown feature bits 0x%x", c->features);
+	NEED(c->Nz <= 65535u && (uint64_t)c->Nx*c->Ny < 0xFFFFFF00ull, "lattice %ux%ux%u exceeds the launch limits (Nz <= 65535, Nx*Ny < 2^32)", c->Nx, c->Ny, c->Nz);
 	for (int ax = 0; ax < 3; ax++) {
 		const uint32_t n = ax == 0 ? c->Nx : ax == 1 ? c->Ny : c->Nz, dd = ax == 0 ? c->Dx : ax == 1 ? c->Dy : c->Dz;
 		NEED(dd <= 1u || n >= 3u, "an axis with %u domains needs at least 1 cell between its two halo layers (size %u)", dd, n);
@@ -155,11 +173,11 @@ int lbmhip_domain_create(const lbmhip_config* c, lbmhip_domain** out) {
 		}
 	}
 	// defaults of LBM_Domain::allocate (lbm.cpp:164-167, 175): rho = 1, everything else 0; fi is left to initialize()
-	e = hipMemsetAsync(d->field[LBMHIP_FIELD_FI], 0, d->field_bytes[LBMHIP_FIELD_FI], d->stream);
-	if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)d->field[LBMHIP_FIELD_RHO], 0x3F800000, d->N, d->stream);
-	if (e == hipSuccess) e = hipMemsetAsync(d->field[LBMHIP_FIELD_U], 0, d->field_bytes[LBMHIP_FIELD_U], d->stream);
-	if (e == hipSuccess) e = hipMemsetAsync(d->field[LBMHIP_FIELD_FLAGS], 0, d->field_bytes[LBMHIP_FIELD_FLAGS], d->stream);
-	if (e == hipSuccess && d->field[LBMHIP_FIELD_F]) e = hipMemsetAsync(d->field[LBMHIP_FIELD_F], 0, d->field_bytes[LBMHIP_FIELD_F], d->stream);
+	e = fill_bytes(d->field[LBMHIP_FIELD_FI], 0u, d->field_bytes[LBMHIP_FIELD_FI], d->stream);
+	if (e == hipSuccess) e = fill_words(d->field[LBMHIP_FIELD_RHO], 0x3F800000u, d->N, d->stream);
+	if (e == hipSuccess) e = fill_bytes(d->field[LBMHIP_FIELD_U], 0u, d->field_bytes[LBMHIP_FIELD_U], d->stream);
+	if (e == hipSuccess) e = fill_bytes(d->field[LBMHIP_FIELD_FLAGS], 0u, d->field_bytes[LBMHIP_FIELD_FLAGS], d->stream);
+	if (e == hipSuccess && d->field[LBMHIP_FIELD_F]) e = fill_bytes(d->field[LBMHIP_FIELD_F], 0u, d->field_bytes[LBMHIP_FIELD_F], d->stream);
 	if (e != hipSuccess) { cleanup(); return fail("clearing the fields failed: %s", hipGetErrorString(e)); }
 
 	if (c->Dx*c->Dy*c->Dz > 1u) { // LBM_Domain::allocate_transfer (lbm.cpp:2019-2035): one set of buffers sized for the largest face
@@ -327,14 +345,15 @@ static int launch_collide_planes(lbmhip_domain* d, uint64_t t, float fx, float f
 	Args a = make_args(d, t, fx, fy, fz);
 	a.z0 = z0; a.z1 = z1;
 	a.xchunks = (lanes_per_row+block-1u)/block;
-	const uint64_t blocks = (uint64_t)a.xchunks*d->cfg.Ny*(z1-z0);
-	NEED(blocks <= 0x7FFFFFFFull, "lattice too large for one launch (%llu workgroups)", (unsigned long long)blocks);
+	// one grid dimension carries at most 2^32-1 work-items: x-chunks and y go to grid.x, lattice planes to grid.y
+	const uint64_t blocks_x = (uint64_t)a.xchunks*d->cfg.Ny;
+	NEED(blocks_x*block < 0xFFFFFFFFull && (z1-z0) <= 65535u, "lattice too large for one launch (%llu x %u workgroups)", (unsigned long long)blocks_x, z1-z0);
 	collide_launch_fn fn = find_collide(d, V, fields_only);
 	NEED(fn, "no compiled kernel for D?Q%u storage %u collision %u", d->cfg.velocity_set, d->cfg.storage, d->cfg.collision);
 	DeviceGuard g(d->cfg.device);
 	// dynamic LDS is not used by the kernel; reserving it caps the workgroups resident per CU (160 KiB LDS per CU)
 	const uint32_t lds = blocks_per_cu > 0 ? ((160u*1024u/(uint32_t)blocks_per_cu)&~255u) : 0u;
-	HIP_TRY(fn(a, dim3((uint32_t)blocks), dim3(block), lds, d->stream));
+	HIP_TRY(fn(a, dim3((uint32_t)blocks_x, z1-z0), dim3(block), lds, d->stream));
 	return 0;
 }
 
@@ -346,7 +365,10 @@ static int launch_collide_planes(lbmhip_domain* d, uint64_t t, float fx, float f
 		default: switch (ST_) { case ST_FP32: { constexpr int Q = 27, ST = ST_FP32; CALL; } break; case ST_FP16S: { constexpr int Q = 27, ST = ST_FP16S; CALL; } break; default: { constexpr int Q = 27, ST = ST_FP16C; CALL; } break; } break; \
 	}
 
-static dim3 grid_for(uint64_t n, uint32_t block) { return dim3((uint32_t)((n+block-1u)/block)); }
+static dim3 grid_cells(const lbmhip_domain* d, uint32_t block) { // one lattice plane per grid.y (stays below 2^32 work-items per dimension)
+	const uint64_t plane = (uint64_t)d->cfg.Nx*d->cfg.Ny;
+	return dim3((uint32_t)((plane+block-1u)/block), d->cfg.Nz);
+}
 
 extern "C" {
 
@@ -354,7 +376,7 @@ int lbmhip_initialize(lbmhip_domain* d) {
 	NEED(d, "null domain");
 	DeviceGuard g(d->cfg.device);
 	const Args a = make_args(d, 1u, 0.0f, 0.0f, 0.0f);
-	DISPATCH_Q_ST((int)d->cfg.velocity_set, (int)d->cfg.storage, hipLaunchKernelGGL((k_initialize<Q, ST>), grid_for(d->N, 256u), dim3(256), 0, d->stream, a));
+	DISPATCH_Q_ST((int)d->cfg.velocity_set, (int)d->cfg.storage, hipLaunchKernelGGL((k_initialize<Q, ST>), grid_cells(d, 256u), dim3(256), 0, d->stream, a));
 	HIP_TRY(hipGetLastError());
 	return 0;
 }
@@ -376,7 +398,7 @@ int lbmhip_update_force_field(lbmhip_domain* d, uint64_t t) {
 	NEED(d->field[LBMHIP_FIELD_F], "update_force_field needs the FORCE_FIELD extension");
 	DeviceGuard g(d->cfg.device);
 	const Args a = make_args(d, t, 0.0f, 0.0f, 0.0f);
-	DISPATCH_Q_ST((int)d->cfg.velocity_set, (int)d->cfg.storage, hipLaunchKernelGGL((k_update_force_field<Q, ST>), grid_for(d->N, 256u), dim3(256), 0, d->stream, a));
+	DISPATCH_Q_ST((int)d->cfg.velocity_set, (int)d->cfg.storage, hipLaunchKernelGGL((k_update_force_field<Q, ST>), grid_cells(d, 256u), dim3(256), 0, d->stream, a));
 	HIP_TRY(hipGetLastError());
 	return 0;
 }
@@ -385,7 +407,7 @@ int lbmhip_reset_force_field(lbmhip_domain* d) {
 	NEED(d->field[LBMHIP_FIELD_F], "reset_force_field needs the FORCE_FIELD extension");
 	DeviceGuard g(d->cfg.device);
 	const Args a = make_args(d, 0u, 0.0f, 0.0f, 0.0f);
-	hipLaunchKernelGGL(k_reset_force_field, grid_for(d->N, 256u), dim3(256), 0, d->stream, a);
+	hipLaunchKernelGGL(k_reset_force_field, grid_cells(d, 256u), dim3(256), 0, d->stream, a);
 	HIP_TRY(hipGetLastError());
 	return 0;
 }
@@ -395,10 +417,10 @@ int lbmhip_update_moving_boundaries(lbmhip_domain* d) {
 	DeviceGuard g(d->cfg.device);
 	const Args a = make_args(d, 0u, 0.0f, 0.0f, 0.0f);
 	switch (d->cfg.velocity_set) {
-		case 9: hipLaunchKernelGGL((k_update_moving_boundaries<9>), grid_for(d->N, 256u), dim3(256), 0, d->stream, a); break;
-		case 15: hipLaunchKernelGGL((k_update_moving_boundaries<15>), grid_for(d->N, 256u), dim3(256), 0, d->stream, a); break;
-		case 19: hipLaunchKernelGGL((k_update_moving_boundaries<19>), grid_for(d->N, 256u), dim3(256), 0, d->stream, a); break;
-		default: hipLaunchKernelGGL((k_update_moving_boundaries<27>), grid_for(d->N, 256u), dim3(256), 0, d->stream, a); break;
+		case 9: hipLaunchKernelGGL((k_update_moving_boundaries<9>), grid_cells(d, 256u), dim3(256), 0, d->stream, a); break;
+		case 15: hipLaunchKernelGGL((k_update_moving_boundaries<15>), grid_cells(d, 256u), dim3(256), 0, d->stream, a); break;
+		case 19: hipLaunchKernelGGL((k_update_moving_boundaries<19>), grid_cells(d, 256u), dim3(256), 0, d->stream, a); break;
+		default: hipLaunchKernelGGL((k_update_moving_boundaries<27>), grid_cells(d, 256u), dim3(256), 0, d->stream, a); break;
 	}
 	HIP_TRY(hipGetLastError());
 	return 0;

@@ -1,0 +1,166 @@
+// utilities.hpp - the small part of the reference's utilities.hpp that setups use (FluidX3D-master/src/utilities.hpp):
+// integer typedefs, float3 / float3x3, parallel_for, Clock, console helpers, string helpers.  Written from scratch.
+#pragma once
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <iostream>
+#include <limits>
+#include <string>
+#include <thread>
+#include <vector>
+
+using std::string;
+using std::vector;
+using std::thread;
+using std::min;
+using std::max;
+typedef unsigned char uchar;
+typedef unsigned short ushort;
+typedef unsigned int uint;
+typedef uint64_t ulong;
+typedef int64_t slong;
+
+constexpr float pif = 3.1415927f;
+constexpr double pi = 3.141592653589793;
+constexpr uint max_uint = std::numeric_limits<uint>::max();
+constexpr ulong max_ulong = std::numeric_limits<ulong>::max();
+constexpr double max_double = std::numeric_limits<double>::max();
+
+inline float sq(const float x) { return x*x; }
+inline double sq(const double x) { return x*x; }
+inline uint sq(const uint x) { return x*x; }
+inline float cb(const float x) { return x*x*x; }
+inline float radians(const float degrees) { return degrees*(pif/180.0f); }
+inline float degrees(const float radians) { return radians*(180.0f/pif); }
+inline float sign(const float x) { return x >= 0.0f ? 1.0f : -1.0f; }
+inline float rsqrt(const float x) { return 1.0f/std::sqrt(x); }
+inline uint to_uint(const float x) { return (uint)std::fmax(std::fmin(x+0.5f, 4294967040.0f), 0.0f); }
+inline uint to_uint(const double x) { return (uint)std::fmax(std::fmin(x+0.5, 4294967295.0), 0.0); }
+inline ulong to_ulong(const float x) { return (ulong)std::fmax(x+0.5f, 0.0f); }
+inline uint gcd(uint a, uint b) { while (b) { const uint t = a%b; a = b; b = t; } return a; }
+inline uint lcm(const uint a, const uint b) { return a/gcd(a, b)*b; }
+
+struct uint3 {
+	uint x = 0u, y = 0u, z = 0u;
+	uint3() {}
+	uint3(const uint x, const uint y, const uint z) : x(x), y(y), z(z) {}
+	explicit uint3(const uint v) : x(v), y(v), z(v) {}
+};
+inline uint3 operator/(const uint3& a, const uint b) { return uint3(a.x/b, a.y/b, a.z/b); }
+inline uint3 operator*(const uint3& a, const uint b) { return uint3(a.x*b, a.y*b, a.z*b); }
+
+struct float3 {
+	float x = 0.0f, y = 0.0f, z = 0.0f;
+	float3() {}
+	float3(const float x, const float y, const float z) : x(x), y(y), z(z) {}
+	explicit float3(const float v) : x(v), y(v), z(v) {}
+	float3& operator+=(const float3& b) { x += b.x; y += b.y; z += b.z; return *this; }
+	float3& operator-=(const float3& b) { x -= b.x; y -= b.y; z -= b.z; return *this; }
+	float3& operator*=(const float s) { x *= s; y *= s; z *= s; return *this; }
+};
+inline float3 operator+(const float3& a, const float3& b) { return float3(a.x+b.x, a.y+b.y, a.z+b.z); }
+inline float3 operator-(const float3& a, const float3& b) { return float3(a.x-b.x, a.y-b.y, a.z-b.z); }
+inline float3 operator-(const float3& a) { return float3(-a.x, -a.y, -a.z); }
+inline float3 operator*(const float s, const float3& a) { return float3(s*a.x, s*a.y, s*a.z); }
+inline float3 operator*(const float3& a, const float s) { return float3(s*a.x, s*a.y, s*a.z); }
+inline float3 operator/(const float3& a, const float s) { return float3(a.x/s, a.y/s, a.z/s); }
+inline float dot(const float3& a, const float3& b) { return a.x*b.x+a.y*b.y+a.z*b.z; }
+inline float3 cross(const float3& a, const float3& b) { return float3(a.y*b.z-a.z*b.y, a.z*b.x-a.x*b.z, a.x*b.y-a.y*b.x); }
+inline float length(const float3& a) { return std::sqrt(dot(a, a)); }
+inline float3 normalize(const float3& a, const float s = 1.0f) { const float l = length(a); return l > 0.0f ? a*(s/l) : a; }
+
+struct float3x3 { // row-major 3x3 matrix; float3x3(axis, angle) is the rotation about `axis` by `angle` radians
+	float xx = 1.0f, xy = 0.0f, xz = 0.0f, yx = 0.0f, yy = 1.0f, yz = 0.0f, zx = 0.0f, zy = 0.0f, zz = 1.0f;
+	float3x3() {}
+	explicit float3x3(const float d) : xx(d), yy(d), zz(d) {}
+	float3x3(const float xx, const float xy, const float xz, const float yx, const float yy, const float yz, const float zx, const float zy, const float zz)
+		: xx(xx), xy(xy), xz(xz), yx(yx), yy(yy), yz(yz), zx(zx), zy(zy), zz(zz) {}
+	float3x3(const float3& axis, const float angle) { // Rodrigues rotation formula
+		const float3 n = normalize(axis);
+		const float c = std::cos(angle), s = std::sin(angle), t = 1.0f-c;
+		xx = t*n.x*n.x+c;     xy = t*n.x*n.y-s*n.z; xz = t*n.x*n.z+s*n.y;
+		yx = t*n.y*n.x+s*n.z; yy = t*n.y*n.y+c;     yz = t*n.y*n.z-s*n.x;
+		zx = t*n.z*n.x-s*n.y; zy = t*n.z*n.y+s*n.x; zz = t*n.z*n.z+c;
+	}
+};
+inline float3 operator*(const float3x3& m, const float3& v) { return float3(m.xx*v.x+m.xy*v.y+m.xz*v.z, m.yx*v.x+m.yy*v.y+m.yz*v.z, m.zx*v.x+m.zy*v.y+m.zz*v.z); }
+inline float3x3 operator*(const float3x3& a, const float3x3& b) {
+	return float3x3(a.xx*b.xx+a.xy*b.yx+a.xz*b.zx, a.xx*b.xy+a.xy*b.yy+a.xz*b.zy, a.xx*b.xz+a.xy*b.yz+a.xz*b.zz,
+	                a.yx*b.xx+a.yy*b.yx+a.yz*b.zx, a.yx*b.xy+a.yy*b.yy+a.yz*b.zy, a.yx*b.xz+a.yy*b.yz+a.yz*b.zz,
+	                a.zx*b.xx+a.zy*b.yx+a.zz*b.zx, a.zx*b.xy+a.zy*b.yy+a.zz*b.zy, a.zx*b.xz+a.zy*b.yz+a.zz*b.zz);
+}
+
+// ---- strings and console
+inline string to_string(const string& s) { return s; }
+inline string to_string(const char* s) { return string(s); }
+inline string to_string(const uint x) { return std::to_string(x); }
+inline string to_string(const int x) { return std::to_string(x); }
+inline string to_string(const ulong x) { return std::to_string((unsigned long long)x); }
+inline string to_string(const slong x) { return std::to_string((long long)x); }
+inline string to_string(const float x) { char b[48]; std::snprintf(b, sizeof(b), "%.9g", (double)x); return string(b); } // 9 digits round-trip a float
+inline string to_string(const double x) { char b[64]; std::snprintf(b, sizeof(b), "%.17g", x); return string(b); }
+inline string to_string(const float x, const uint decimals) { char b[64]; std::snprintf(b, sizeof(b), "%.*f", (int)decimals, (double)x); return string(b); }
+inline string to_string(const double x, const uint decimals) { char b[64]; std::snprintf(b, sizeof(b), "%.*f", (int)decimals, x); return string(b); }
+inline uint length(const string& s) { return (uint)s.length(); }
+inline string substring(const string& s, const uint start, const uint n) { return s.substr(start, n); }
+inline void print(const string& s = "") { std::cout << s; }
+inline void println(const string& s = "") { std::cout << s << std::endl; }
+inline void println(const float x) { println(to_string(x)); }
+inline void print_info(const string& s) { println("| Info: "+s); }
+inline void print_warning(const string& s) { println("| Warning: "+s); }
+[[noreturn]] inline void print_error(const string& s) { // the reference prints and exits on every error (utilities.hpp:4159-4166)
+	std::cerr << "| Error: " << s << std::endl;
+	std::exit(1);
+}
+inline string print_time(const double seconds) {
+	const ulong t = (ulong)std::max(seconds, 0.0);
+	char b[64]; std::snprintf(b, sizeof(b), "%llud %02lluh %02llum %02llus", (unsigned long long)(t/86400ull), (unsigned long long)(t%86400ull/3600ull), (unsigned long long)(t%3600ull/60ull), (unsigned long long)(t%60ull));
+	return string(b);
+}
+inline void sleep(const double seconds) { std::this_thread::sleep_for(std::chrono::microseconds((long long)(seconds*1E6))); }
+inline void wait() {}
+string get_exe_path(); // directory of the running executable with trailing '/', defined in lbm.cpp
+void create_folder(const string& path_to_file); // creates the directories leading to a file, defined in lbm.cpp
+inline string create_file_extension(const string& filename, const string& extension) {
+	const size_t dot = filename.rfind('.'), slash = filename.rfind('/');
+	const bool has = dot != string::npos && (slash == string::npos || dot > slash);
+	return (has ? filename.substr(0, dot) : filename)+(extension.empty() || extension[0] == '.' ? extension : "."+extension);
+}
+
+class Clock {
+	std::chrono::high_resolution_clock::time_point t0;
+public:
+	Clock() { start(); }
+	void start() { t0 = std::chrono::high_resolution_clock::now(); }
+	double stop() const { return std::chrono::duration<double>(std::chrono::high_resolution_clock::now()-t0).count(); }
+};
+
+// ---- parallel_for(N, [threads,] f(n[, t])): static split of [0,N) over host threads (utilities.hpp:60-93)
+template <class F> inline void parallel_for(const ulong N, const uint threads, F&& f) {
+	const uint T = (uint)std::max<ulong>(1ull, std::min<ulong>(threads ? threads : 1u, N));
+	auto body = [&](const uint t) {
+		const ulong a = N*(ulong)t/(ulong)T, b = N*(ulong)(t+1u)/(ulong)T;
+		for (ulong n = a; n < b; n++) {
+			if constexpr (std::is_invocable<F, ulong, uint>::value) f(n, t); else f(n);
+		}
+	};
+	if (T == 1u) { body(0u); return; }
+	vector<thread> pool;
+	for (uint t = 0u; t < T; t++) pool.emplace_back(body, t);
+	for (thread& th : pool) th.join();
+}
+template <class F> inline void parallel_for(const ulong N, F&& f) { parallel_for(N, (uint)thread::hardware_concurrency(), std::forward<F>(f)); }
+
+// uniform pseudo-random numbers in [0, x] from a caller-held seed
+inline float random(uint& seed, const float x = 1.0f) { seed = seed*1664525u+1013904223u; return x*(float)(seed>>8)*(1.0f/16777215.0f); }
+
+template <class T> inline T reverse_bytes(const T value) {
+	T r; const char* a = (const char*)&value; char* b = (char*)&r;
+	for (size_t i = 0; i < sizeof(T); i++) b[i] = a[sizeof(T)-1u-i];
+	return r;
+}

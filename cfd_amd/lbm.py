@@ -78,21 +78,35 @@ class Domain:
         self.h = C.c_void_p()
         check(lib().lbmhip_domain_create(C.byref(cfg), C.byref(self.h)))
         self.N = cfg.Nx * cfg.Ny * cfg.Nz
-        self.rho = np.ones(self.N, dtype=np.float32)
-        self.u = np.zeros(3 * self.N, dtype=np.float32)
-        self.flags = np.zeros(self.N, dtype=np.uint8)
-        self.F = np.zeros(3 * self.N, dtype=np.float32) if cfg.features & FEATURES["FORCE_FIELD"] else None
+        self.has_F = bool(cfg.features & FEATURES["FORCE_FIELD"])
+        self._host = {}
+
+    # host mirrors are allocated on first use (a 1600^3 lattice has 70 GB of them; callers that keep data on the device
+    # never touch them)
+    def _mirror(self, name, count, dtype, fill):
+        if name not in self._host:
+            self._host[name] = np.full(count, fill, dtype=dtype)
+        return self._host[name]
+
+    @property
+    def rho(self): return self._mirror("rho", self.N, np.float32, 1.0)
+    @property
+    def u(self): return self._mirror("u", 3 * self.N, np.float32, 0.0)
+    @property
+    def flags(self): return self._mirror("flags", self.N, np.uint8, 0)
+    @property
+    def F(self): return self._mirror("F", 3 * self.N, np.float32, 0.0) if self.has_F else None
 
     def close(self):
         if self.h:
             lib().lbmhip_domain_destroy(self.h)
             self.h = C.c_void_p()
 
-    def upload(self, field, a):
-        check(lib().lbmhip_upload(self.h, field, a.ctypes.data_as(C.c_void_p), C.c_uint64(0), C.c_uint64(a.nbytes)))
+    def upload(self, field, a, offset=0):
+        check(lib().lbmhip_upload(self.h, field, a.ctypes.data_as(C.c_void_p), C.c_uint64(offset), C.c_uint64(a.nbytes)))
 
-    def download(self, field, a):
-        check(lib().lbmhip_download(self.h, field, a.ctypes.data_as(C.c_void_p), C.c_uint64(0), C.c_uint64(a.nbytes)))
+    def download(self, field, a, offset=0):
+        check(lib().lbmhip_download(self.h, field, a.ctypes.data_as(C.c_void_p), C.c_uint64(offset), C.c_uint64(a.nbytes)))
 
     def download_fi(self):
         dt = np.float32 if self.cfg.storage == 0 else np.uint16

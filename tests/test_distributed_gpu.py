@@ -1,0 +1,115 @@
+"""GPU: the one-process-per-GPU runner (cfd_amd.distributed) with the HIP slab engine.  Two ranks share the one GPU of
+the test box and exchange halos over gloo (host-staged rehearsal of the RCCL path); the result must equal the oracle's
+two-domain run bit for bit.  Also: the largest single-GPU lattice of the benchmark configurations."""
+import ctypes as C
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, kw, steps, overlap, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cfd_amd import setups
+        from cfd_amd.distributed import DistributedLBM
+        kw = dict(kw)
+        lbm = DistributedLBM(kw.pop("N"), rank=rank, world=world, overlap=overlap, **kw)
+        setups.channel(lbm)
+        lbm.run(steps)
+        lbm.read_from_device()
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), rho=lbm.rho, u=lbm.u, flags=lbm.flags)
+        lbm.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_two_ranks_on_one_gpu_match_the_oracle(gpu, tmp_path, overlap):
+    sys.path.insert(0, ROOT)
+    from cfd_amd import setups
+    from oracle import harness as H
+    world, steps = 2, 20
+    kw = dict(N=(64, 32, 48), nu=0.01, Q=19, storage="FP32", collision="TRT", features=("VOLUME_FORCE", "SUBGRID"), f=(1e-4, 0.0, 0.0))
+    mp.spawn(_worker, args=(world, _free_port(), kw, steps, overlap, str(tmp_path)), nprocs=world, join=True)
+    ref = H.OracleLBM(kw["N"], kw["nu"], D=(1, 1, world), Q=19, collision="TRT", features=kw["features"], f=kw["f"])
+    setups.channel(ref)
+    ref.run(steps)
+    ref.read_from_device()
+    nz = kw["N"][2] // world
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        sl = slice(r * nz, (r + 1) * nz)
+        assert np.array_equal(got["flags"], ref.flags[sl])
+        assert np.array_equal(got["rho"].view(np.uint32), ref.rho[sl].view(np.uint32))
+        assert np.array_equal(got["u"].view(np.uint32), ref.u[:, sl].view(np.uint32))
+
+
+def test_capacity_lattice_1600_fp16s(gpu):
+    """D3Q19 FP16S at 1600^3 (4.1e9 cells, 225 GB: the capacity configuration of the benchmark list).  Only a small
+    block of cells is disturbed, so for a few steps its neighbourhood must evolve exactly like the same block in a small
+    periodic box computed by the oracle - a check of 64-bit indexing at the far end of a 155 GB allocation."""
+    import cfd_amd
+    from cfd_amd import lbm as L
+    from oracle import harness as H
+    free, total = C.c_uint64(), C.c_uint64()
+    L.check(cfd_amd.lib().lbmhip_device_memory(0, C.byref(free), C.byref(total)))
+    n = 1600
+    need = n ** 3 * cfd_amd.lib().lbmhip_bytes_per_cell_device(19, 1, 0)
+    if free.value < need * 1.01:
+        n = int((free.value * 0.95 / 55) ** (1.0 / 3.0)) // 64 * 64  # whatever fits (reported in the assertion messages)
+    assert n >= 1024, "less than 62 GB of device memory free: %d" % free.value
+    small, steps, blob = 48, 6, 8
+    cfg = L.Config(n, n, n, 1, 1, 1, 0, 0, 0, 19, L.STORAGE["FP16S"], 0, 0, 0.02, 0)
+    dom = L.Domain(cfg)
+    try:
+        lib = cfd_amd.lib()
+        N = n ** 3
+        assert N * 19 > 2 ** 32  # DDF element offsets need 64 bits
+        # velocity blob near the END of the lattice: rows of `blob` cells at (x0.., y, z) with x0,y,z around n-24
+        base = n - small // 2 - blob // 2
+        rng = np.random.RandomState(3)
+        ux = (rng.rand(blob, blob, blob).astype(np.float32) - 0.5) * 0.1
+        for dz in range(blob):
+            for dy in range(blob):
+                off = ((base + dz) * n + (base + dy)) * n + base
+                dom.upload(L.FIELD_U, np.ascontiguousarray(ux[dz, dy]), offset=off * 4)
+        L.check(lib.lbmhip_initialize(dom.h))
+        for t in range(steps):
+            L.check(lib.lbmhip_stream_collide(dom.h, C.c_uint64(t), C.c_float(0), C.c_float(0), C.c_float(0)))
+        L.check(lib.lbmhip_update_fields(dom.h, C.c_uint64(steps), C.c_float(0), C.c_float(0), C.c_float(0)))
+        L.check(lib.lbmhip_sync(dom.h))
+        # read back the small box around the blob, row by row
+        o = n - small
+        got = np.empty((3, small, small, small), dtype=np.float32)
+        row = np.empty(small, dtype=np.float32)
+        for c in range(3):
+            for z in range(small):
+                for y in range(small):
+                    dom.download(L.FIELD_U, row, offset=(c * N + ((o + z) * n + (o + y)) * n + o) * 4)
+                    got[c, z, y] = row
+    finally:
+        dom.close()
+    ref = H.OracleLBM((small, small, small), 0.02, storage="FP16S")
+    b0 = small // 2 - blob // 2
+    ref.u[0, b0:b0 + blob, b0:b0 + blob, b0:b0 + blob] = ux
+    ref.run(steps)
+    ref.read_from_device()
+    assert np.abs(got).max() > 1e-3
+    assert np.array_equal(got.view(np.uint32), ref.u.view(np.uint32)), "n=%d" % n
