@@ -7,3 +7,4 @@ a GPU, every compute call needs the library and a device.
 """
 from .lbm import LBM, LbmHipError, lib, lib_path, FEATURES, STORAGE, COLLISION  # noqa: F401
 from . import setups  # noqa: F401
+from . import mesh  # noqa: F401

@@ -358,6 +358,116 @@ __global__ __launch_bounds__(256) void k_halo_fields(const HaloArgs h, const uin
 	}
 }
 
+// ---------------------------------------------------------------------------------------------- mesh voxelizer
+// FluidX3D-master/src/kernel.cpp:2295-2390.  One lane per cell of the face perpendicular to `direction`: a ray along
+// the axis, bidirectional Moeller-Trumbore against every triangle, the hits ahead kept as truncated 16-bit distances
+// and sorted, then the column is walked and the cells between an odd and the next even hit are flagged.  Plain float
+// arithmetic in a fixed order (dot = (ax*bx+ay*by)+az*bz) so that the flag lattice is reproducible bit for bit.
+struct VoxelArgs {
+	Args lat;
+	const float* p0; const float* p1; const float* p2; // 3 floats per triangle each
+	uint32_t triangles, direction;
+	int32_t O[3];
+	float lo[3], hi[3];  // bounding box of the mesh, widened by 2 cells (lbm.cpp:352-358)
+	float rc[3], lin[3], rot[3];
+	uint8_t flag;
+};
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 v3sub(V3 a, V3 b) { return {a.x-b.x, a.y-b.y, a.z-b.z}; }
+__device__ __forceinline__ V3 v3add(V3 a, V3 b) { return {a.x+b.x, a.y+b.y, a.z+b.z}; }
+__device__ __forceinline__ float v3dot(V3 a, V3 b) { return a.x*b.x+a.y*b.y+a.z*b.z; }
+__device__ __forceinline__ V3 v3cross(V3 a, V3 b) { return {a.y*b.z-a.z*b.y, a.z*b.x-a.x*b.z, a.x*b.y-a.y*b.x}; }
+__device__ __forceinline__ int clampi(int x, int lo, int hi) { return x < lo ? lo : x > hi ? hi : x; }
+__device__ __forceinline__ V3 cell_position(const VoxelArgs& v, uint32_t x, uint32_t y, uint32_t z) { // kernel.cpp:834-836, 2306
+	const Args& a = v.lat;
+	const V3 p = {(float)x+0.5f-0.5f*(float)a.Nx, (float)y+0.5f-0.5f*(float)a.Ny, (float)z+0.5f-0.5f*(float)a.Nz};
+	const V3 off = {0.5f*(float)((int)a.Nx+2*v.O[0])-0.5f, 0.5f*(float)((int)a.Ny+2*v.O[1])-0.5f, 0.5f*(float)((int)a.Nz+2*v.O[2])-0.5f};
+	return v3add(p, off);
+}
+template <int Q, int ST> __global__ __launch_bounds__(64) void k_voxelize_mesh(const VoxelArgs v) {
+	using S = Store<ST>; using raw = typename S::raw;
+	const Args& a = v.lat;
+	const uint32_t dirn = v.direction;
+	const uint32_t A = dirn == 0u ? a.Ny*a.Nz : dirn == 1u ? a.Nz*a.Nx : a.Nx*a.Ny;
+	const uint32_t fa = blockIdx.x*blockDim.x+threadIdx.x;
+	if (fa >= A) return;
+	const int Nd[3] = {(int)a.Nx, (int)a.Ny, (int)a.Nz};
+	uint32_t c[3];
+	const uint32_t start = (uint32_t)clampi((int)v.lo[dirn]-v.O[dirn], 0, Nd[dirn]-1);
+	if (dirn == 0u) { c[0] = start; c[1] = fa%a.Ny; c[2] = fa/a.Ny; }
+	else if (dirn == 1u) { c[0] = fa/a.Nz; c[1] = start; c[2] = fa%a.Nz; }
+	else { c[0] = fa%a.Nx; c[1] = fa/a.Nx; c[2] = start; }
+	const V3 origin = cell_position(v, c[0], c[1], c[2]);
+	const V3 dirv = {(float)(dirn == 0u), (float)(dirn == 1u), (float)(dirn == 2u)};
+	const bool outside = dirn == 0u ? (origin.y < v.lo[1] || origin.z < v.lo[2] || origin.y >= v.hi[1] || origin.z >= v.hi[2])
+	                   : dirn == 1u ? (origin.x < v.lo[0] || origin.z < v.lo[2] || origin.x >= v.hi[0] || origin.z >= v.hi[2])
+	                   : (origin.x < v.lo[0] || origin.y < v.lo[1] || origin.x >= v.hi[0] || origin.y >= v.hi[1]);
+	if (outside) return;
+	uint32_t ahead = 0u, behind = 0u;
+	uint16_t dist[64];
+	for (uint32_t i = 0u; i < 64u; i++) dist[i] = 0u;
+	for (uint32_t i = 0u; i < v.triangles; i++) {
+		const V3 a0 = {v.p0[3u*i], v.p0[3u*i+1u], v.p0[3u*i+2u]}, a1 = {v.p1[3u*i], v.p1[3u*i+1u], v.p1[3u*i+2u]}, a2 = {v.p2[3u*i], v.p2[3u*i+1u], v.p2[3u*i+2u]};
+		const V3 e1 = v3sub(a1, a0), e2 = v3sub(a2, a0), w = v3sub(origin, a0), h = v3cross(dirv, e2), q = v3cross(w, e1);
+		const float g = v3dot(e1, h), f = 1.0f/g, s = f*v3dot(w, h), tt = f*v3dot(dirv, q), d = f*v3dot(e2, q);
+		if (g != 0.0f && s >= 0.0f && s < 1.0f && tt >= 0.0f && s+tt < 1.0f) {
+			if (d > 0.0f) { if (ahead < 64u && d < 65536.0f) dist[ahead] = (uint16_t)d; ahead++; }
+			else behind++;
+		}
+	}
+	const uint32_t kept = ahead < 64u ? ahead : 64u;
+	for (uint32_t i = 1u; i < kept; i++) { // insertion sort, ascending
+		const uint16_t val = dist[i]; uint32_t j = i;
+		while (j > 0u && dist[j-1u] > val) { dist[j] = dist[j-1u]; j--; }
+		dist[j] = val;
+	}
+	bool inside = (ahead%2u) && (behind%2u);
+	const V3 lin = {v.lin[0], v.lin[1], v.lin[2]}, rot = {v.rot[0], v.rot[1], v.rot[2]}, rc = {v.rc[0], v.rc[1], v.rc[2]};
+	const bool set_u = lin.x*lin.x+lin.y*lin.y+lin.z*lin.z+rot.x*rot.x+rot.y*rot.y+rot.z*rot.z > 0.0f;
+	uint32_t next = (ahead%2u) != (behind%2u);
+	const uint32_t h0 = c[dirn];
+	const uint32_t hmax = (uint32_t)clampi((int)v.hi[dirn]-v.O[dirn], 0, Nd[dirn]);
+	const uint32_t last = ahead-1u < 63u ? ahead-1u : 63u;
+	const uint32_t hmesh = h0+(uint32_t)dist[last];
+	for (uint32_t hc = h0; hc < hmax; hc++) {
+		while (next < ahead && hc > h0+(uint32_t)dist[next < 63u ? next : 63u]) { inside = !inside; next++; }
+		inside = inside && (next < ahead && hc < hmesh);
+		uint32_t cc[3] = {c[0], c[1], c[2]}; cc[dirn] = hc;
+		const uint64_t n = (uint64_t)cc[0]+((uint64_t)cc[1]+(uint64_t)cc[2]*a.Ny)*a.Nx;
+		uint8_t fl = a.flags[n];
+		const V3 p = cell_position(v, cc[0], cc[1], cc[2]);
+		const V3 u_set = v3add(lin, v3cross(v3sub(rc, p), rot));
+		if (inside) {
+			fl = (uint8_t)((fl&~TYPE_BO)|v.flag);
+			if (set_u) { a.u[n] = u_set.x; a.u[a.N+n] = u_set.y; a.u[2ull*a.N+n] = u_set.z; }
+		} else if ((fl&TYPE_BO) == TYPE_S) {
+			const float ux = a.u[n], uy = a.u[a.N+n], uz = a.u[2ull*a.N+n];
+			if (ux == u_set.x && uy == u_set.y && uz == u_set.z) { // the cell belonged to this mesh: release it
+				if (set_u) { // give the freed cell equilibrium DDFs at rho=1 (kernel.cpp:2367-2373)
+					uint64_t j[Q]; neighbors<Q>(a, cc[0], cc[1], cc[2], j);
+					float feq[Q]; f_eq<Q>(1.0f, ux, uy, uz, feq);
+					raw* fi = static_cast<raw*>(a.fi);
+					fi[n] = S::encode(feq[0]);
+					static_for<1, Q, 2>([&](auto I) {
+						constexpr int i = I;
+						fi[(uint64_t)(a.odd ? i+1 : i)*a.N+j[i]] = S::encode(feq[i]);
+						fi[(uint64_t)(a.odd ? i : i+1)*a.N+n] = S::encode(feq[i+1]);
+					});
+				}
+				fl = (fl&TYPE_BO) == TYPE_MS ? (uint8_t)(fl&~TYPE_MS) : (uint8_t)(fl&~v.flag);
+			}
+		}
+		a.flags[n] = fl;
+	}
+}
+// FluidX3D-master/src/kernel.cpp:2386-2390
+__global__ __launch_bounds__(256) void k_unvoxelize_mesh(const VoxelArgs v) {
+	const Cell c = cell_of_thread(v.lat);
+	if (!c.valid) return;
+	const V3 p = cell_position(v, c.x, c.y, c.z);
+	if (p.x >= v.lo[0]-1.0f && p.y >= v.lo[1]-1.0f && p.z >= v.lo[2]-1.0f && p.x <= v.hi[0]+1.0f && p.y <= v.hi[1]+1.0f && p.z <= v.hi[2]+1.0f) v.lat.flags[c.n] &= (uint8_t)~v.flag;
+}
+
 #endif // LBM_SMALL_KERNELS
 
 } // namespace lbm

@@ -534,6 +534,54 @@ int lbmhip_halo_exchange_local(lbmhip_domain** doms, uint32_t count, int what, i
 	return 0;
 }
 
+// ---------------------------------------------------------------------------------------------- mesh voxelizer
+int lbmhip_voxelize_mesh(lbmhip_domain* d, uint32_t direction, uint64_t t, uint8_t flag, const float* p0, const float* p1, const float* p2, uint32_t triangles,
+                         const float* bounding_box, const float* rotation_center, const float* linear_velocity, const float* rotational_velocity) {
+	NEED(d && p0 && p1 && p2 && bounding_box, "null argument");
+	NEED(direction < 3u, "direction must be 0, 1 or 2");
+	NEED(triangles > 0u, "mesh without triangles");
+	DeviceGuard g(d->cfg.device);
+	const size_t bytes = (size_t)triangles*3u*sizeof(float);
+	float* dev = nullptr;
+	HIP_TRY(hipMalloc(&dev, 3u*bytes));
+	hipError_t e = hipMemcpyAsync(dev, p0, bytes, hipMemcpyHostToDevice, d->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(dev+(size_t)triangles*3u, p1, bytes, hipMemcpyHostToDevice, d->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(dev+(size_t)triangles*6u, p2, bytes, hipMemcpyHostToDevice, d->stream);
+	if (e != hipSuccess) { (void)hipFree(dev); return fail("uploading the mesh failed: %s", hipGetErrorString(e)); }
+	VoxelArgs v;
+	v.lat = make_args(d, t, 0.0f, 0.0f, 0.0f);
+	v.p0 = dev; v.p1 = dev+(size_t)triangles*3u; v.p2 = dev+(size_t)triangles*6u;
+	v.triangles = triangles; v.direction = direction; v.flag = flag;
+	v.O[0] = d->cfg.Ox; v.O[1] = d->cfg.Oy; v.O[2] = d->cfg.Oz;
+	for (int k = 0; k < 3; k++) {
+		v.lo[k] = bounding_box[k]; v.hi[k] = bounding_box[3+k];
+		v.rc[k] = rotation_center ? rotation_center[k] : 0.0f;
+		v.lin[k] = linear_velocity ? linear_velocity[k] : 0.0f;
+		v.rot[k] = rotational_velocity ? rotational_velocity[k] : 0.0f;
+	}
+	const uint64_t A = face_area(d, (int)direction);
+	const dim3 grid((uint32_t)((A+63u)/64u)), block(64);
+	DISPATCH_Q_ST((int)d->cfg.velocity_set, (int)d->cfg.storage, hipLaunchKernelGGL((k_voxelize_mesh<Q, ST>), grid, block, 0, d->stream, v));
+	e = hipGetLastError();
+	if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+	(void)hipFree(dev);
+	if (e != hipSuccess) return fail("voxelize_mesh failed: %s", hipGetErrorString(e));
+	return 0;
+}
+int lbmhip_unvoxelize_mesh(lbmhip_domain* d, uint8_t flag, const float* bounding_box) {
+	NEED(d && bounding_box, "null argument");
+	DeviceGuard g(d->cfg.device);
+	VoxelArgs v;
+	memset(&v, 0, sizeof(v));
+	v.lat = make_args(d, 0u, 0.0f, 0.0f, 0.0f);
+	v.flag = flag;
+	v.O[0] = d->cfg.Ox; v.O[1] = d->cfg.Oy; v.O[2] = d->cfg.Oz;
+	for (int k = 0; k < 3; k++) { v.lo[k] = bounding_box[k]; v.hi[k] = bounding_box[3+k]; }
+	hipLaunchKernelGGL(k_unvoxelize_mesh, grid_cells(d, 256u), dim3(256), 0, d->stream, v);
+	HIP_TRY(hipGetLastError());
+	return 0;
+}
+
 // ---------------------------------------------------------------------------------------------- timing
 int lbmhip_timer_start(lbmhip_domain* d) {
 	NEED(d, "null domain");

@@ -88,6 +88,36 @@ string default_filename(const string& name, const string& extension, const ulong
 
 static void check(const int status) { if (status) print_error(lbmhip_last_error()); }
 
+Mesh* read_stl(const string& path, const float3& box_size, const float3& center, const float3x3& rotation, const float size) {
+	const string filename = create_file_extension(path, ".stl");
+	std::ifstream file(filename, std::ios::in|std::ios::binary);
+	if (file.fail()) print_error("File \""+filename+"\" does not exist!");
+	vector<char> data((std::istreambuf_iterator<char>(file)), std::istreambuf_iterator<char>());
+	if (data.size() < 84u) print_error("File \""+filename+"\" is corrupt!");
+	uint triangle_number = 0u;
+	std::memcpy(&triangle_number, data.data()+80, 4);
+	if (triangle_number == 0u || data.size() != 84ull+50ull*(ulong)triangle_number) print_error("File \""+filename+"\" is corrupt or unsupported! Only binary .stl files are supported.");
+	print_info("Loading \""+filename+"\" with "+to_string(triangle_number)+" triangles.");
+	Mesh* mesh = new Mesh(triangle_number, center);
+	for (uint i = 0u; i < triangle_number; i++) { // 50 bytes per triangle: normal, three corners, attribute
+		float v[12];
+		std::memcpy(v, data.data()+84ull+50ull*(ulong)i, 48);
+		mesh->p0[i] = rotation*float3(v[3], v[4], v[5]);
+		mesh->p1[i] = rotation*float3(v[6], v[7], v[8]);
+		mesh->p2[i] = rotation*float3(v[9], v[10], v[11]);
+	}
+	mesh->find_bounds();
+	const float scale = size == 0.0f ? mesh->get_scale_for_box_fit(box_size) : size > 0.0f ? size/mesh->get_max_size() : -size;
+	const float3 offset = -0.5f*(mesh->pmin+mesh->pmax);
+	for (uint i = 0u; i < triangle_number; i++) {
+		mesh->p0[i] = center+scale*(offset+mesh->p0[i]);
+		mesh->p1[i] = center+scale*(offset+mesh->p1[i]);
+		mesh->p2[i] = center+scale*(offset+mesh->p2[i]);
+	}
+	mesh->find_bounds();
+	return mesh;
+}
+
 // ---------------------------------------------------------------------------------------------- LBM_Domain
 LBM_Domain::LBM_Domain(const int device, const uint Nx, const uint Ny, const uint Nz, const uint Dx, const uint Dy, const uint Dz, const int Ox, const int Oy, const int Oz, const float nu, const float fx, const float fy, const float fz)
 	: Nx(Nx), Ny(Ny), Nz(Nz), Dx(Dx), Dy(Dy), Dz(Dz), Ox(Ox), Oy(Oy), Oz(Oz), nu(nu), fx(fx), fy(fy), fz(fz) {
@@ -369,6 +399,48 @@ void LBM::update_moving_boundaries() {
 	for (LBM_Domain* d : lbm_domain) d->finish_queue();
 }
 #endif
+
+// LBM_Domain::voxelize_mesh_on_device (lbm.cpp:344-412) for every domain, then LBM::voxelize_mesh_on_device (lbm.cpp:1645-1670)
+void LBM::voxelize_mesh_on_device(const Mesh* mesh, const uchar flag, const float3& rotation_center, const float3& linear_velocity, const float3& rotational_velocity) {
+	const float box[6] = {mesh->pmin.x-2.0f, mesh->pmin.y-2.0f, mesh->pmin.z-2.0f, mesh->pmax.x+2.0f, mesh->pmax.y+2.0f, mesh->pmax.z+2.0f};
+	uint direction = 0u;
+	if (length(rotational_velocity) == 0.0f) { // rays along the axis with the smallest bounding-box cross-section
+		const float v[3] = {(box[4]-box[1])*(box[5]-box[2]), (box[5]-box[2])*(box[3]-box[0]), (box[3]-box[0])*(box[4]-box[1])};
+		for (uint i = 1u; i < 3u; i++) if (v[i] < v[direction]) direction = i;
+	} else { // rays along the axis closest to the rotation axis
+		const float v[3] = {std::fabs(rotational_velocity.x), std::fabs(rotational_velocity.y), std::fabs(rotational_velocity.z)};
+		for (uint i = 1u; i < 3u; i++) if (v[i] > v[direction]) direction = i;
+	}
+	vector<float> p0(3u*mesh->triangle_number), p1(3u*mesh->triangle_number), p2(3u*mesh->triangle_number);
+	for (uint i = 0u; i < mesh->triangle_number; i++) {
+		p0[3u*i] = mesh->p0[i].x; p0[3u*i+1u] = mesh->p0[i].y; p0[3u*i+2u] = mesh->p0[i].z;
+		p1[3u*i] = mesh->p1[i].x; p1[3u*i+1u] = mesh->p1[i].y; p1[3u*i+2u] = mesh->p1[i].z;
+		p2[3u*i] = mesh->p2[i].x; p2[3u*i+1u] = mesh->p2[i].y; p2[3u*i+2u] = mesh->p2[i].z;
+	}
+	const float rc[3] = {rotation_center.x, rotation_center.y, rotation_center.z}, lin[3] = {linear_velocity.x, linear_velocity.y, linear_velocity.z}, rot[3] = {rotational_velocity.x, rotational_velocity.y, rotational_velocity.z};
+	for (LBM_Domain* d : lbm_domain) check(lbmhip_voxelize_mesh(d->handle, direction, d->get_t()+1ull, flag, p0.data(), p1.data(), p2.data(), mesh->triangle_number, box, rc, lin, rot));
+#ifdef MOVING_BOUNDARIES
+	if ((flag&(TYPE_S|TYPE_E)) == TYPE_S && (length(linear_velocity) > 0.0f || length(rotational_velocity) > 0.0f)) update_moving_boundaries();
+#endif
+	if (!initialized) { // the host copies follow the device until the first run()
+		for (LBM_Domain* d : lbm_domain) { d->flags.read_from_device(); d->u.read_from_device(); }
+	}
+}
+void LBM::unvoxelize_mesh_on_device(const Mesh* mesh, const uchar flag) {
+	const float box[6] = {mesh->pmin.x, mesh->pmin.y, mesh->pmin.z, mesh->pmax.x, mesh->pmax.y, mesh->pmax.z};
+	for (LBM_Domain* d : lbm_domain) check(lbmhip_unvoxelize_mesh(d->handle, flag, box));
+	for (LBM_Domain* d : lbm_domain) d->finish_queue();
+}
+void LBM::voxelize_stl(const string& path, const float3& center, const float3x3& rotation, const float size, const uchar flag) {
+	const Mesh* mesh = read_stl(path, this->size(), center, rotation, size);
+	flags.write_to_device();
+	voxelize_mesh_on_device(mesh, flag);
+	delete mesh;
+	for (LBM_Domain* d : lbm_domain) d->flags.read_from_device();
+}
+void LBM::voxelize_stl(const string& path, const float3x3& rotation, const float size, const uchar flag) { voxelize_stl(path, center(), rotation, size, flag); }
+void LBM::voxelize_stl(const string& path, const float3& center, const float size, const uchar flag) { voxelize_stl(path, center, float3x3(1.0f), size, flag); }
+void LBM::voxelize_stl(const string& path, const float size, const uchar flag) { voxelize_stl(path, center(), float3x3(1.0f), size, flag); }
 
 void LBM::write_status(const string& path) { // lbm.cpp:1599-1643: key = value lines
 	const string filename = default_filename(path, "status", ".txt", get_t());

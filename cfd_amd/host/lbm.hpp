@@ -207,5 +207,12 @@ public:
 	float3 relative_position(const ulong n) const { uint x, y, z; coordinates(n, x, y, z); return relative_position(x, y, z); }
 	void write_status(const string& path = ""); // lbm.cpp:1599-1643
 
+	void voxelize_mesh_on_device(const Mesh* mesh, const uchar flag = TYPE_S, const float3& rotation_center = float3(0.0f), const float3& linear_velocity = float3(0.0f), const float3& rotational_velocity = float3(0.0f)); // lbm.cpp:1645-1670
+	void unvoxelize_mesh_on_device(const Mesh* mesh, const uchar flag = TYPE_S);
+	void voxelize_stl(const string& path, const float3& center, const float3x3& rotation, const float size = 0.0f, const uchar flag = TYPE_S); // lbm.cpp:1728-1752
+	void voxelize_stl(const string& path, const float3x3& rotation, const float size = 0.0f, const uchar flag = TYPE_S);
+	void voxelize_stl(const string& path, const float3& center, const float size = 0.0f, const uchar flag = TYPE_S);
+	void voxelize_stl(const string& path, const float size = 0.0f, const uchar flag = TYPE_S);
+
 	friend class LBM_Domain;
 };

@@ -159,6 +159,27 @@ template <class F> inline void parallel_for(const ulong N, F&& f) { parallel_for
 // uniform pseudo-random numbers in [0, x] from a caller-held seed
 inline float random(uint& seed, const float x = 1.0f) { seed = seed*1664525u+1013904223u; return x*(float)(seed>>8)*(1.0f/16777215.0f); }
 
+// ---- triangle mesh and binary STL reader (FluidX3D-master/src/utilities.hpp:4440-4581)
+struct Mesh {
+	uint triangle_number = 0u;
+	float3 center, pmin, pmax;
+	vector<float3> p0, p1, p2; // the three corners of every triangle
+	Mesh(const uint triangle_number, const float3& center) : triangle_number(triangle_number), center(center), pmin(center), pmax(center), p0(triangle_number), p1(triangle_number), p2(triangle_number) {}
+	void find_bounds() {
+		pmin = pmax = p0[0];
+		for (uint i = 0u; i < triangle_number; i++) for (const float3& p : {p0[i], p1[i], p2[i]}) {
+			pmin = float3(std::fmin(p.x, pmin.x), std::fmin(p.y, pmin.y), std::fmin(p.z, pmin.z));
+			pmax = float3(std::fmax(p.x, pmax.x), std::fmax(p.y, pmax.y), std::fmax(p.z, pmax.z));
+		}
+	}
+	float get_max_size() const { return std::fmax(std::fmax(pmax.x-pmin.x, pmax.y-pmin.y), pmax.z-pmin.z); }
+	float get_scale_for_box_fit(const float3& box) const { return std::fmin(std::fmin(box.x/(pmax.x-pmin.x), box.y/(pmax.y-pmin.y)), box.z/(pmax.z-pmin.z)); }
+	float3 get_bounding_box_size() const { return pmax-pmin; }
+	float3 get_bounding_box_center() const { return 0.5f*(pmin+pmax); }
+};
+// rotate, rescale (size 0: largest that fits the box; >0: longest side = size; <0: factor -size) and re-centre on `center`
+Mesh* read_stl(const string& path, const float3& box_size, const float3& center, const float3x3& rotation, const float size); // defined in lbm.cpp
+
 template <class T> inline T reverse_bytes(const T value) {
 	T r; const char* a = (const char*)&value; char* b = (char*)&r;
 	for (size_t i = 0; i < sizeof(T); i++) b[i] = a[sizeof(T)-1u-i];

@@ -10,6 +10,7 @@ import os
 import numpy as np
 
 from . import decomposition
+from . import mesh as meshlib
 
 STORAGE = {"FP32": 0, "FP16S": 1, "FP16C": 2}
 COLLISION = {"SRT": 0, "TRT": 1}
@@ -335,3 +336,42 @@ class LBM:
 
     def reset(self):
         self.initialized = False
+
+    # ---- LBM::voxelize_mesh_on_device / voxelize_stl (lbm.cpp:1645-1670, 1728-1752)
+    def voxelize_mesh_on_device(self, mesh, flag=TYPE_S, rotation_center=(0, 0, 0), linear_velocity=(0, 0, 0), rotational_velocity=(0, 0, 0)):
+        direction, bbox, rc, lin, rot = meshlib.voxelize_parameters(mesh, rotation_center, linear_velocity, rotational_velocity)
+        fp = lambda a: np.ascontiguousarray(a, dtype=np.float32).ctypes.data_as(C.c_void_p)
+        p0, p1, p2 = (np.ascontiguousarray(p, dtype=np.float32) for p in (mesh.p0, mesh.p1, mesh.p2))
+        for dom in self.domains:
+            check(self._L.lbmhip_voxelize_mesh(dom.h, C.c_uint32(direction), C.c_uint64(self.t + 1), C.c_uint8(flag), fp(p0), fp(p1), fp(p2),
+                                               C.c_uint32(mesh.triangle_number), fp(bbox), fp(rc), fp(lin), fp(rot)))
+        if not self.initialized:  # the host copies follow the device until the first run() (lbm.cpp:1666-1669)
+            self._read_raw(("flags", "u"))
+
+    def unvoxelize_mesh_on_device(self, mesh, flag=TYPE_S):
+        bbox = np.concatenate([mesh.pmin, mesh.pmax]).astype(np.float32)
+        for dom in self.domains:
+            check(self._L.lbmhip_unvoxelize_mesh(dom.h, C.c_uint8(flag), bbox.ctypes.data_as(C.c_void_p)))
+        self.sync()
+
+    def voxelize_stl(self, path, center=None, rotation=None, size=0.0, flag=TYPE_S):
+        c = self.center() if center is None else center
+        m = meshlib.read_stl(path, self.size(), c, rotation, size)
+        self.write_to_device(("flags",))
+        self.voxelize_mesh_on_device(m, flag)
+        self._read_raw(("flags",))
+        return m
+
+    def _read_raw(self, fields):
+        """Device -> host copies without the update_fields refresh (used before the simulation is initialized)."""
+        was, self.initialized = self.initialized, False
+        try:
+            self.read_from_device(fields)
+        finally:
+            self.initialized = was
+
+    def size(self):
+        return tuple(float(v) for v in self.N)
+
+    def center(self):
+        return tuple(0.5 * float(v) - 0.5 for v in self.N)

@@ -127,6 +127,16 @@ int lbmhip_halo_set_buffers(lbmhip_domain* domain, void* send_p, void* send_m, v
  * ordered d = x+(y+z*Dy)*Dx.  Orders the copies after each domain's pack and before its unpack. */
 int lbmhip_halo_exchange_local(lbmhip_domain** domains, uint32_t count, int what, int axis);
 
+/* ---- mesh voxelizer: LBM_Domain::voxelize_mesh_on_device / enqueue_unvoxelize_mesh_on_device (lbm.cpp:344-422) and the
+ * kernels voxelize_mesh / unvoxelize_mesh (kernel.cpp:2295-2390).  p0, p1, p2: HOST arrays of 3*triangles floats (the three
+ * corners of every triangle, in global lattice coordinates); bounding_box: x0 y0 z0 x1 y1 z1 of the mesh widened by 2
+ * cells; direction: axis the rays travel along; t: the reference passes get_t()+1.  The velocity arguments may be NULL
+ * (resting geometry).  Complete when the call returns. */
+int lbmhip_voxelize_mesh(lbmhip_domain* domain, uint32_t direction, uint64_t t, uint8_t flag, const float* p0, const float* p1, const float* p2,
+                         uint32_t triangles, const float* bounding_box, const float* rotation_center, const float* linear_velocity,
+                         const float* rotational_velocity);
+int lbmhip_unvoxelize_mesh(lbmhip_domain* domain, uint8_t flag, const float* bounding_box);
+
 /* ---- timing on the handle's stream (the reference only has a host clock, lbm.cpp:1481-1483) */
 int lbmhip_timer_start(lbmhip_domain* domain);
 int lbmhip_timer_stop(lbmhip_domain* domain, float* milliseconds); /* waits for the stream */

@@ -73,6 +73,10 @@ class PortEngine:
     def update_moving_boundaries(self, u, flags):
         self.lib.oracle_update_moving_boundaries(self.c, _p(u), _p(flags))
 
+    def voxelize_mesh(self, O, direction, fi, u, flags, t, flag, p0, p1, p2, params):
+        off = (C.c_int * 3)(*O)
+        self.lib.oracle_voxelize_mesh(self.c, off, C.c_uint32(direction), _p(fi), _p(u), _p(flags), C.c_uint64(t), C.c_uint8(flag), _p(p0), _p(p1), _p(p2), _p(params))
+
     def transfer_fi(self, insert, axis, t, p, m, fi):
         self.lib.oracle_transfer_fi(self.c, int(insert), C.c_uint32(axis), C.c_uint64(t), _p(p), _p(m), _p(fi))
 
@@ -114,6 +118,9 @@ class RefEngine:
 
     def update_moving_boundaries(self, u, flags):
         assert self.lib.ref_update_moving_boundaries(_p(u), _p(flags), 1) == 0
+
+    def voxelize_mesh(self, O, direction, fi, u, flags, t, flag, p0, p1, p2, params):
+        self.lib.ref_voxelize_mesh(C.c_uint32(direction), _p(fi), _p(u), _p(flags), C.c_uint64(t), C.c_uint8(flag), _p(p0), _p(p1), _p(p2), _p(params))
 
     def transfer_fi(self, insert, axis, t, p, m, fi):
         self.lib.ref_transfer_fi(int(insert), C.c_uint32(axis), C.c_uint64(t), _p(p), _p(m), _p(fi))

@@ -487,6 +487,109 @@ void oracle_transfer_F(const oracle_cfg* cfg, int insert, uint32_t axis, void* b
 	}
 }
 
+
+/* ------------------------------------------------------------------------------------------------
+ * mesh voxelizer (kernel.cpp:2295-2390): one ray per cell of the domain face perpendicular to `direction`,
+ * bidirectional Moeller-Trumbore against every triangle, distances of the hits ahead kept as truncated
+ * 16-bit integers and sorted, then the lattice column is walked and cells between odd and even hits
+ * are flagged.  params = the 16 floats the reference packs (lbm.cpp:351-374): triangle count (as bits),
+ * bounding box x0 y0 z0 x1 y1 z1 (+-2 cells), rotation centre, linear velocity, rotational velocity.
+ * Plain float arithmetic, no fused operations: dot = (ax*bx+ay*by)+az*bz, cross by components.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { float x, y, z; } vec3;
+static vec3 v3(float x, float y, float z) { vec3 r = {x, y, z}; return r; }
+static vec3 vsub(vec3 a, vec3 b) { return v3(a.x-b.x, a.y-b.y, a.z-b.z); }
+static vec3 vadd(vec3 a, vec3 b) { return v3(a.x+b.x, a.y+b.y, a.z+b.z); }
+static float vdot(vec3 a, vec3 b) { return a.x*b.x+a.y*b.y+a.z*b.z; }
+static vec3 vcross(vec3 a, vec3 b) { return v3(a.y*b.z-a.z*b.y, a.z*b.x-a.x*b.z, a.x*b.y-a.y*b.x); }
+static int clampi(int x, int lo, int hi) { return x < lo ? lo : x > hi ? hi : x; }
+/* cell centre in global lattice coordinates: position() (kernel.cpp:834-836) plus the domain offset (kernel.cpp:2306) */
+static vec3 cell_position(const oracle_cfg* cfg, const int* O, uint32_t x, uint32_t y, uint32_t z) {
+	const vec3 p = v3((float)x+0.5f-0.5f*(float)cfg->Nx, (float)y+0.5f-0.5f*(float)cfg->Ny, (float)z+0.5f-0.5f*(float)cfg->Nz);
+	const vec3 off = v3(0.5f*(float)((int)cfg->Nx+2*O[0])-0.5f, 0.5f*(float)((int)cfg->Ny+2*O[1])-0.5f, 0.5f*(float)((int)cfg->Nz+2*O[2])-0.5f);
+	return vadd(p, off);
+}
+void oracle_voxelize_mesh(const oracle_cfg* cfg, const int* O, uint32_t direction, void* fi, float* u, uint8_t* flags, uint64_t t, uint8_t flag,
+                          const float* p0, const float* p1, const float* p2, const float* params) {
+	const uint64_t N = cells(cfg), A = face_area(cfg, direction);
+	uint32_t triangle_number; memcpy(&triangle_number, &params[0], 4);
+	const float x0 = params[1], y0 = params[2], z0 = params[3], x1 = params[4], y1 = params[5], z1 = params[6];
+	const vec3 rc = v3(params[7], params[8], params[9]), lin = v3(params[10], params[11], params[12]), rot = v3(params[13], params[14], params[15]);
+	const int Nd[3] = {(int)cfg->Nx, (int)cfg->Ny, (int)cfg->Nz};
+	const float lo[3] = {x0, y0, z0}, hi[3] = {x1, y1, z1};
+	for (uint32_t a = 0u; a < (uint32_t)A; a++) {
+		uint32_t c[3];
+		const uint32_t start = (uint32_t)clampi((int)lo[direction]-O[direction], 0, Nd[direction]-1);
+		if (direction == 0u) { c[0] = start; c[1] = a%cfg->Ny; c[2] = a/cfg->Ny; }
+		else if (direction == 1u) { c[0] = a/cfg->Nz; c[1] = start; c[2] = a%cfg->Nz; }
+		else { c[0] = a%cfg->Nx; c[1] = a/cfg->Nx; c[2] = start; }
+		const vec3 origin = cell_position(cfg, O, c[0], c[1], c[2]);
+		const vec3 dirv = v3((float)(direction == 0u), (float)(direction == 1u), (float)(direction == 2u));
+		const int outside = direction == 0u ? (origin.y < y0 || origin.z < z0 || origin.y >= y1 || origin.z >= z1)
+		                  : direction == 1u ? (origin.x < x0 || origin.z < z0 || origin.x >= x1 || origin.z >= z1)
+		                  : (origin.x < x0 || origin.y < y0 || origin.x >= x1 || origin.y >= y1);
+		if (outside) continue;
+		uint32_t ahead = 0u, behind = 0u;
+		uint16_t dist[64];
+		for (uint32_t i = 0u; i < 64u; i++) dist[i] = 0u;
+		for (uint32_t i = 0u; i < triangle_number; i++) {
+			const vec3 a0 = v3(p0[3u*i], p0[3u*i+1u], p0[3u*i+2u]), a1 = v3(p1[3u*i], p1[3u*i+1u], p1[3u*i+2u]), a2 = v3(p2[3u*i], p2[3u*i+1u], p2[3u*i+2u]);
+			const vec3 e1 = vsub(a1, a0), e2 = vsub(a2, a0), w = vsub(origin, a0), h = vcross(dirv, e2), q = vcross(w, e1);
+			const float g = vdot(e1, h), f = 1.0f/g, s = f*vdot(w, h), tt = f*vdot(dirv, q), d = f*vdot(e2, q);
+			if (g != 0.0f && s >= 0.0f && s < 1.0f && tt >= 0.0f && s+tt < 1.0f) {
+				if (d > 0.0f) { if (ahead < 64u && d < 65536.0f) dist[ahead] = (uint16_t)d; ahead++; }
+				else behind++;
+			}
+		}
+		const uint32_t kept = ahead < 64u ? ahead : 64u;
+		for (uint32_t i = 1u; i < kept; i++) { /* ascending */
+			const uint16_t v = dist[i]; uint32_t j = i;
+			while (j > 0u && dist[j-1u] > v) { dist[j] = dist[j-1u]; j--; }
+			dist[j] = v;
+		}
+		int inside = (ahead%2u) && (behind%2u);
+		const int set_u = lin.x*lin.x+lin.y*lin.y+lin.z*lin.z+rot.x*rot.x+rot.y*rot.y+rot.z*rot.z > 0.0f;
+		uint32_t next = (ahead%2u) != (behind%2u); /* parity disagreement: skip the first hit */
+		const uint32_t h0 = c[direction];
+		const uint32_t hmax = (uint32_t)clampi((int)hi[direction]-O[direction], 0, Nd[direction]);
+		const uint32_t last = ahead-1u < 63u ? ahead-1u : 63u; /* ahead==0 wraps to 63 like the reference's min(intersections-1u, 63u) */
+		const uint32_t hmesh = h0+(uint32_t)dist[last];
+		for (uint32_t hcell = h0; hcell < hmax; hcell++) {
+			while (next < ahead && hcell > h0+(uint32_t)dist[next < 63u ? next : 63u]) { inside = !inside; next++; }
+			inside = inside && (next < ahead && hcell < hmesh);
+			uint32_t cc[3] = {c[0], c[1], c[2]}; cc[direction] = hcell;
+			const uint64_t n = cell_index(cfg, cc[0], cc[1], cc[2]);
+			uint8_t fl = flags[n];
+			const vec3 p = cell_position(cfg, O, cc[0], cc[1], cc[2]);
+			const vec3 u_set = vadd(lin, vcross(vsub(rc, p), rot));
+			if (inside) {
+				fl = (uint8_t)((fl&~TYPE_BO)|flag);
+				if (set_u) { u[n] = u_set.x; u[N+n] = u_set.y; u[2u*N+n] = u_set.z; }
+			} else if ((fl&TYPE_BO) == TYPE_S) {
+				const float ux = u[n], uy = u[N+n], uz = u[2u*N+n];
+				if (ux == u_set.x && uy == u_set.y && uz == u_set.z) { /* the cell belonged to this mesh: release it */
+					if (set_u) {
+						uint64_t j[27]; neighbors(cfg, cc[0], cc[1], cc[2], j);
+						float feq[27]; f_eq(cfg, 1.0f, ux, uy, uz, feq);
+						store_f(cfg, fi, n, j, t, feq);
+					}
+					fl = (fl&TYPE_BO) == TYPE_MS ? (uint8_t)(fl&~TYPE_MS) : (uint8_t)(fl&~flag);
+				}
+			}
+			flags[n] = fl;
+		}
+	}
+}
+/* kernel.cpp:2386-2390 */
+void oracle_unvoxelize_mesh(const oracle_cfg* cfg, const int* O, uint8_t* flags, uint8_t flag, float x0, float y0, float z0, float x1, float y1, float z1) {
+	const uint64_t N = cells(cfg);
+	for (uint64_t n = 0u; n < N; n++) {
+		uint32_t x, y, z; coordinates(cfg, n, &x, &y, &z);
+		const vec3 p = cell_position(cfg, O, x, y, z);
+		if (p.x >= x0-1.0f && p.y >= y0-1.0f && p.z >= z0-1.0f && p.x <= x1+1.0f && p.y <= y1+1.0f && p.z <= z1+1.0f) flags[n] &= (uint8_t)~flag;
+	}
+}
+
 /* storage-format converters exposed so tests can pin them against numpy float16 and the reference */
 float oracle_half_to_float(uint16_t h) { return half_to_float(h); }
 uint16_t oracle_float_to_half(float x) { return float_to_half_rte(x); }

@@ -147,7 +147,7 @@ def build_all(cfgs, force=False):
                     "-DREF_TRANSFERS=%d" % transfers, "-DREF_FPXX_BYTES=%d" % (4 if cfg["storage"] == "FP32" else 2)]
             defs += ["-DREF_%s" % f for f in cfg["features"]]
             so = os.path.join(OUT, "libref_%s.so" % tag)
-            run([CLANG + "++", "-std=c++17", "-O2", "-mfma", "-fPIC", "-shared", "-pthread"] + defs +
+            run([CLANG + "++", "-std=c++17", "-O2", "-mfma", "-ffp-contract=off", "-fPIC", "-shared", "-pthread"] + defs +
                 [os.path.join(HERE, "cl_host.cpp"), clobj, "-o", so])
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

@@ -95,6 +95,8 @@ void transfer__insert_F(uint direction, ulong t, const float* p, const float* m,
 #ifdef REF_MOVING_BOUNDARIES
 void update_moving_boundaries(const float* u, uchar* flags);
 #endif
+void voxelize_mesh(uint direction, fpxx* fi, float* u, uchar* flags, ulong t, uchar flag, const float* p0, const float* p1, const float* p2, const float* bbu);
+void unvoxelize_mesh(uchar* flags, uchar flag, float x0, float y0, float z0, float x1, float y1, float z1);
 void transfer_extract_fi(uint direction, ulong t, fpxx* p, fpxx* m, const fpxx* fi);
 void transfer__insert_fi(uint direction, ulong t, const fpxx* p, const fpxx* m, fpxx* fi);
 void transfer_extract_rho_u_flags(uint direction, ulong t, char* p, char* m, const float* rho, const float* u, const uchar* flags);
@@ -186,6 +188,12 @@ API int ref_update_moving_boundaries(const float* u, uchar* flags, int threads) 
 	(void)u; (void)flags; (void)threads;
 	return -1;
 #endif
+}
+API void ref_voxelize_mesh(uint direction, void* fi, float* u, uchar* flags, ulong t, uchar flag, const float* p0, const float* p1, const float* p2, const float* bbu) {
+	ndrange(area(direction), 1, [=]() { voxelize_mesh(direction, (fpxx*)fi, u, flags, t, flag, p0, p1, p2, bbu); });
+}
+API void ref_unvoxelize_mesh(uchar* flags, uchar flag, float x0, float y0, float z0, float x1, float y1, float z1) {
+	ndrange(N, 1, [=]() { unvoxelize_mesh(flags, flag, x0, y0, z0, x1, y1, z1); });
 }
 API void ref_transfer_fi(int insert, uint direction, ulong t, void* p, void* m, void* fi) {
 	if (insert) ndrange(area(direction), 1, [=]() { transfer__insert_fi(direction, t, (const fpxx*)p, (const fpxx*)m, (fpxx*)fi); });

@@ -26,6 +26,13 @@ def case_config(tag, kw):
 def all_configs():
     from tests.cases import CASES
     cfgs = [case_config(name, c["kw"]) for name, c in sorted(CASES.items())]
+    from tests.voxel_cases import VOXEL_CASES
+    for name, c in sorted(VOXEL_CASES.items()):  # the voxelizer reads the baked-in domain offset: one library per domain
+        D = c["D"]
+        for d in range(D[0] * D[1] * D[2]):
+            cfg = case_config("voxel_%s_d%d" % (name, d), dict(N=c["N"], D=D, nu=0.01))
+            cfg["O"] = decomposition.domain_offset(d, decomposition.rounded_size(c["N"], D), D)
+            cfgs.append(cfg)
     cfgs.append(case_config("bench_tgv256", dict(N=(256, 256, 256), nu=0.01)))
     cfgs.append(case_config("cavity128", dict(N=(128, 128, 128), nu=0.0126, features=("MOVING_BOUNDARIES",))))
     return cfgs

@@ -22,6 +22,7 @@ sys.path.insert(0, ROOT)
 
 from oracle import harness as H  # noqa: E402
 from tests.cases import CASES  # noqa: E402
+from tests.voxel_cases import VOXEL_CASES, voxelize_with_engine  # noqa: E402
 
 
 def crc(a):
@@ -55,6 +56,12 @@ def main():
         np.savez_compressed(os.path.join(out_dir, name + ".npz"), meta=json.dumps(meta), pins=json.dumps(pins), flags=ref.flags,
                             rho_sub=ref.rho[::2, ::2, ::2], u_sub=ref.u[:, ::2, ::2, ::2])
         print(name, pins["crc_rho"], pins["crc_u"], "%.6f" % pins["sum_rho"])
+    # voxelizer fixtures: flags (complete) and the CRC of u from the reference's voxelize_mesh kernel
+    for name, case in sorted(VOXEL_CASES.items()):
+        flags, u = voxelize_with_engine(case, lambda local, D, d, n=name: H.RefEngine("voxel_%s_d%d" % (n, d)))
+        np.savez_compressed(os.path.join(out_dir, "voxel_" + name + ".npz"), flags=flags, crc_u=np.uint32(crc(u)),
+                            meta=json.dumps({"case": name, "generator": "oracle/_ref voxelize_mesh, tests/golden/make_golden.py"}))
+        print("voxel", name, int(flags.sum()), crc(u))
 
 
 if __name__ == "__main__":

@@ -59,3 +59,12 @@ def test_config_validation_messages():
     bad = L.Config(16, 16, 2, 1, 1, 1, 0, 0, 0, 9, 0, 0, 0, 0.1, 0)
     assert lib.lbmhip_domain_create(C.byref(bad), C.byref(h)) != 0 and b"D2Q9" in lib.lbmhip_last_error()
     assert not h.value
+
+
+def test_fluid_wrapper_exports_the_symbols_solver_py_binds():
+    path = os.path.join(ROOT, "cfd_amd", "libfluid_wrapper.so")
+    assert os.path.exists(path), "make -C cfd_amd/host"
+    lib = C.CDLL(path)
+    for n in ("fluid_init", "fluid_step", "fluid_get_velocity", "fluid_cleanup"):
+        assert hasattr(lib, n)
+    lib.fluid_cleanup()  # harmless without a simulation

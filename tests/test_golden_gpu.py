@@ -64,3 +64,40 @@ def test_decomposition_invariance_at_scale(gpu):
     rho2, u2 = _run(N, 12, D=(1, 1, 4))
     assert np.array_equal(rho0.view(np.uint32), rho1.view(np.uint32)) and np.array_equal(u0.view(np.uint32), u1.view(np.uint32))
     assert np.array_equal(rho0.view(np.uint32), rho2.view(np.uint32)) and np.array_equal(u0.view(np.uint32), u2.view(np.uint32))
+
+
+# ---- mesh voxelizer on the GPU against the reference fixtures
+import os  # noqa: E402
+
+from tests.voxel_cases import VOXEL_CASES, build_mesh  # noqa: E402
+from tests.test_oracle_golden import GOLDEN  # noqa: E402
+
+
+@pytest.mark.parametrize("name", sorted(VOXEL_CASES))
+def test_hip_voxelizer_reproduces_reference_fixture(gpu, name):
+    case = VOXEL_CASES[name]
+    z = np.load(os.path.join(GOLDEN, "voxel_" + name + ".npz"), allow_pickle=False)
+    with cfd_amd.LBM(case["N"], 0.01, D=case["D"]) as lbm:
+        vel = case["vel"] or ((0, 0, 0), (0, 0, 0), (0, 0, 0))
+        lbm.write_to_device(("flags", "u"))
+        lbm.voxelize_mesh_on_device(build_mesh(case), 1, *vel)
+        assert np.array_equal(lbm.flags, z["flags"])
+        assert crc(lbm.u) == int(z["crc_u"])
+
+
+def test_voxelize_stl_then_run(gpu, tmp_path):
+    """The GUI's path (main.py:145-198): voxelize an STL, TYPE_E faces, inflow velocity, run."""
+    from cfd_amd import mesh as M
+    path = str(tmp_path / "body.stl")
+    M.write_stl(path, *M.uv_sphere())
+    with cfd_amd.LBM((48, 48, 48), 0.01, storage="FP16S", features=("EQUILIBRIUM_BOUNDARIES", "SUBGRID", "UPDATE_FIELDS")) as lbm:
+        lbm.voxelize_stl(path, size=0.4 * 48)
+        solid = lbm.flags == 1
+        assert 3000 < solid.sum() < 4500  # a sphere of diameter 19.2 cells
+        lbm.u[0][~solid] = 0.075
+        face = np.zeros_like(solid); face[0] = face[-1] = True; face[:, 0] = face[:, -1] = True; face[:, :, 0] = face[:, :, -1] = True
+        lbm.flags[face] = 2
+        lbm.run(50)
+        lbm.read_from_device()
+        assert np.isfinite(lbm.u).all() and (lbm.flags[solid] == 1).all()
+        assert np.abs(lbm.u[0][~solid & ~face] - 0.075).max() > 1e-3  # the body disturbs the flow

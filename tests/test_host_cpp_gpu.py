@@ -57,3 +57,48 @@ def test_cavity_example_runs(gpu):
         lbm.read_from_device()
         want = float(lbm.u[1, 126, 64, 64])
     assert value == pytest.approx(want, rel=1e-6, abs=1e-9)  # identical inputs: identical result
+
+
+def test_gui_template_example(gpu, tmp_path):
+    """The setup main.py generates: resolution(), voxelize_stl, TYPE_E faces, key_9 export, run loop, write_status."""
+    from cfd_amd import mesh as M
+    stl = str(tmp_path / "body.stl")
+    M.write_stl(stl, *M.torus())
+    out = run_example("gui_template", env={"LBM_EXAMPLE_STL": stl, "LBM_EXAMPLE_STEPS": "60"})
+    line = [l for l in out.splitlines() if l.startswith("grid ")][0]
+    m = re.fullmatch(r"grid (\d+)x(\d+)x(\d+) solid (\d+) t (\d+)", line)
+    nx, ny, nz, solid, t = (int(v) for v in m.groups())
+    assert nx == ny == nz and 70 <= nx <= 80       # 24 MB at 55 B/cell (D3Q19 FP16S)
+    assert solid > 500 and t == 60
+    for name, kind, comps in (("u", "float", 3), ("rho", "float", 1), ("flags", "unsigned_char", 1)):
+        raw = open(os.path.join(BIN, "export", "%s-000000000.vtk" % name), "rb").read()
+        head = raw[:raw.index(b"LOOKUP_TABLE default\n")].decode()
+        assert "SCALARS data %s %d" % (kind, comps) in head and "DIMENSIONS %d %d %d" % (nx, ny, nz) in head
+    assert os.path.exists(os.path.join(BIN, "export", "status-000000060.txt"))
+
+
+def test_fluid_wrapper_as_solver_py_binds_it(gpu, tmp_path):
+    import ctypes
+    from cfd_amd import mesh as M
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(BIN.rstrip("/")), "..", "libfluid_wrapper.so"))
+    lib.fluid_init.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_char_p]   # solver.py:95-98
+    lib.fluid_step.argtypes = [ctypes.c_int]
+    ptr = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+    lib.fluid_get_velocity.argtypes = [ptr, ptr, ptr]
+    stl = str(tmp_path / "pillar.stl")
+    M.write_stl(stl, *M.box(0.3, 0.3, 1.0))
+    res = 48
+    lib.fluid_init(res, 0.01, 0.0005, stl.encode())
+    lib.fluid_step(20)
+    lib.fluid_step(20)
+    vx, vy, vz = (np.zeros(res ** 3, dtype=np.float32) for _ in range(3))
+    lib.fluid_get_velocity(vx, vy, vz)
+    lib.fluid_cleanup()
+    with cfd_amd.LBM((res, res, res), 0.01, features=("VOLUME_FORCE", "UPDATE_FIELDS"), f=(0.0, 0.0, 0.0005)) as lbm:
+        lbm.voxelize_stl(stl, size=0.9 * res)
+        lbm.run(40)
+        lbm.read_from_device()
+        assert (lbm.flags == 1).sum() > 1000
+        assert np.array_equal(vx.reshape(res, res, res).view(np.uint32), lbm.u[0].view(np.uint32))
+        assert np.array_equal(vz.reshape(res, res, res).view(np.uint32), lbm.u[2].view(np.uint32))
+    assert vz.max() > 1e-3 and np.isfinite(vx).all()

@@ -77,3 +77,31 @@ def test_two_step_bounce_back():
     mass = float(lbm.rho[1:-1].sum(dtype=np.float64))
     assert abs(mass - 8 * 8 * 10) < 0.1           # walls only park mass for one step (mailbox slots), they do not create or destroy it
     assert abs(float(lbm.u[2].sum(dtype=np.float64))) < abs(m1)  # the walls have absorbed z-momentum
+
+
+# ---- mesh voxelizer
+from tests.voxel_cases import VOXEL_CASES, voxelize_with_engine  # noqa: E402
+
+
+@pytest.mark.parametrize("name", sorted(VOXEL_CASES))
+def test_port_voxelizer_reproduces_reference_fixture(name):
+    case = VOXEL_CASES[name]
+    z = np.load(os.path.join(GOLDEN, "voxel_" + name + ".npz"), allow_pickle=False)
+    flags, u = voxelize_with_engine(case, lambda local, D, d: H.PortEngine(local, D, 19, "FP32", "SRT", (), 0.01))
+    assert flags.sum() > 100
+    assert np.array_equal(flags, z["flags"])
+    assert crc(u) == int(z["crc_u"])
+
+
+def test_stl_round_trip(tmp_path):
+    from cfd_amd import mesh as M
+    p0, p1, p2 = M.torus()
+    path = str(tmp_path / "torus.stl")
+    M.write_stl(path, p0, p1, p2)
+    a = M.read_stl(path, (40, 40, 40), (19.5, 19.5, 19.5), None, 30.0)
+    b = M.place(p0, p1, p2, (40, 40, 40), (19.5, 19.5, 19.5), None, 30.0)
+    assert a.triangle_number == 1024 and np.array_equal(a.p0, b.p0) and np.array_equal(a.p2, b.p2)
+    assert abs(float(a.get_max_size()) - 30.0) < 1e-4
+    assert np.allclose(0.5 * (a.pmin + a.pmax), (19.5, 19.5, 19.5), atol=1e-4)
+    with pytest.raises(ValueError):
+        open(path, "ab").write(b"x"); M.read_stl(path, (40, 40, 40), (0, 0, 0))
