@@ -468,6 +468,43 @@ __global__ __launch_bounds__(256) void k_unvoxelize_mesh(const VoxelArgs v) {
 	if (p.x >= v.lo[0]-1.0f && p.y >= v.lo[1]-1.0f && p.z >= v.lo[2]-1.0f && p.x <= v.hi[0]+1.0f && p.y <= v.hi[1]+1.0f && p.z <= v.hi[2]+1.0f) v.lat.flags[c.n] &= (uint8_t)~v.flag;
 }
 
+// ---------------------------------------------------------------------------------------------- object sums
+// Sums over all cells whose flags equal `marker` (FluidX3D-master/src/kernel.cpp:1929-1987): what = 0 positions and cell
+// count (centre of mass), 1 boundary force F, 2 torque (r - centre) x F.  The reference reduces 64 cells in LDS and adds
+// the group sums with float atomics, so its result depends on the order the atomics land; here every workgroup writes
+// one partial sum (wave shuffles, then LDS across the 4 waves) and the host adds the partials in double: reproducible.
+// skip_halo = 0 is the reference kernel's own definition for one domain (every cell of the array, positions from the
+// domain's own centre); skip_halo = 1 leaves halo layers to their owners and measures from the centre of the global box.
+struct SumArgs { Args lat; float4* partial; uint32_t what; uint8_t marker; uint8_t skip_halo; float hx, hy, hz, cx, cy, cz; int32_t O[3]; };
+__global__ __launch_bounds__(256) void k_object_sum(const SumArgs s) {
+	const Args& a = s.lat;
+	const uint64_t plane = (uint64_t)a.Nx*a.Ny;
+	float4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+	for (uint64_t n = (uint64_t)blockIdx.x*blockDim.x+threadIdx.x; n < a.N; n += (uint64_t)gridDim.x*blockDim.x) {
+		const uint32_t z = (uint32_t)(n/plane), r = (uint32_t)(n%plane), y = r/a.Nx, x = r%a.Nx;
+		const bool halo = (a.hx && (x == 0u || x == a.Nx-1u)) || (a.hy && (y == 0u || y == a.Ny-1u)) || (a.hz && (z == 0u || z == a.Nz-1u));
+		if ((s.skip_halo && halo) || a.flags[n] != s.marker) continue;
+		// position() of kernel.cpp:834-836: coordinate + 0.5 - 0.5*size, then minus the rotation centre (kernel.cpp:1975)
+		const float px = (float)((int)x+s.O[0])+0.5f-s.hx-s.cx, py = (float)((int)y+s.O[1])+0.5f-s.hy-s.cy, pz = (float)((int)z+s.O[2])+0.5f-s.hz-s.cz;
+		if (s.what == 0u) { acc.x += px; acc.y += py; acc.z += pz; acc.w += 1.0f; }
+		else {
+			const float fx = a.F[n], fy = a.F[a.N+n], fz = a.F[2ull*a.N+n];
+			if (s.what == 1u) { acc.x += fx; acc.y += fy; acc.z += fz; }
+			else { acc.x += py*fz-pz*fy; acc.y += pz*fx-px*fz; acc.z += px*fy-py*fx; }
+			acc.w += 1.0f;
+		}
+	}
+	for (int off = 32; off > 0; off >>= 1) { acc.x += __shfl_down(acc.x, off); acc.y += __shfl_down(acc.y, off); acc.z += __shfl_down(acc.z, off); acc.w += __shfl_down(acc.w, off); }
+	__shared__ float4 wave[4];
+	if ((threadIdx.x&63u) == 0u) wave[threadIdx.x>>6] = acc;
+	__syncthreads();
+	if (threadIdx.x == 0u) {
+		float4 t = wave[0];
+		for (int w = 1; w < 4; w++) { t.x += wave[w].x; t.y += wave[w].y; t.z += wave[w].z; t.w += wave[w].w; }
+		s.partial[blockIdx.x] = t;
+	}
+}
+
 #endif // LBM_SMALL_KERNELS
 
 } // namespace lbm

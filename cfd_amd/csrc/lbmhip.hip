@@ -582,6 +582,38 @@ int lbmhip_unvoxelize_mesh(lbmhip_domain* d, uint8_t flag, const float* bounding
 	return 0;
 }
 
+// ---------------------------------------------------------------------------------------------- object sums
+int lbmhip_object_sum(lbmhip_domain* d, int what, uint8_t flag_marker, const float* center, const uint32_t* global_size, double* sums) {
+	NEED(d && sums, "null argument");
+	NEED(what >= 0 && what <= 2, "what must be 0 (centre of mass), 1 (force) or 2 (torque)");
+	NEED(what == 0 || d->field[LBMHIP_FIELD_F], "force and torque sums need the FORCE_FIELD extension");
+	DeviceGuard g(d->cfg.device);
+	const uint32_t blocks = 2048u;
+	float4* partial = nullptr;
+	HIP_TRY(hipMalloc(&partial, blocks*sizeof(float4)));
+	SumArgs s;
+	s.lat = make_args(d, 0u, 0.0f, 0.0f, 0.0f);
+	s.partial = partial; s.what = (uint32_t)what; s.marker = flag_marker;
+	s.skip_halo = global_size ? 1u : 0u;
+	s.O[0] = global_size ? d->cfg.Ox : 0; s.O[1] = global_size ? d->cfg.Oy : 0; s.O[2] = global_size ? d->cfg.Oz : 0;
+	s.hx = 0.5f*(float)(global_size ? global_size[0] : d->cfg.Nx);
+	s.hy = 0.5f*(float)(global_size ? global_size[1] : d->cfg.Ny);
+	s.hz = 0.5f*(float)(global_size ? global_size[2] : d->cfg.Nz);
+	s.cx = (what == 2 && center) ? center[0] : 0.0f;
+	s.cy = (what == 2 && center) ? center[1] : 0.0f;
+	s.cz = (what == 2 && center) ? center[2] : 0.0f;
+	hipLaunchKernelGGL(k_object_sum, dim3(blocks), dim3(256), 0, d->stream, s);
+	hipError_t e = hipGetLastError();
+	std::vector<float4> host(blocks);
+	if (e == hipSuccess) e = hipMemcpyAsync(host.data(), partial, blocks*sizeof(float4), hipMemcpyDeviceToHost, d->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+	(void)hipFree(partial);
+	if (e != hipSuccess) return fail("object sum failed: %s", hipGetErrorString(e));
+	sums[0] = sums[1] = sums[2] = sums[3] = 0.0;
+	for (uint32_t b = 0u; b < blocks; b++) { sums[0] += host[b].x; sums[1] += host[b].y; sums[2] += host[b].z; sums[3] += host[b].w; }
+	return 0;
+}
+
 // ---------------------------------------------------------------------------------------------- timing
 int lbmhip_timer_start(lbmhip_domain* d) {
 	NEED(d, "null domain");

@@ -365,30 +365,31 @@ void LBM::update_force_field() { // lbm.cpp:1503-1508
 	for (LBM_Domain* d : lbm_domain) d->enqueue_update_force_field();
 	for (LBM_Domain* d : lbm_domain) d->finish_queue();
 }
-// Sums over all cells whose flags equal flag_marker (lbm.cpp:1509-1554).  The reference reduces on the device with float
-// atomics and adds the domains on the host; here the fields are read back and summed in double on the host cores.
+// Sums over all cells whose flags equal flag_marker (lbm.cpp:1509-1554): reduced on every domain's GPU, added on the host.
+static void object_sums(LBM* lbm, const int what, const uchar flag_marker, const float3& center, double* total) {
+	const uint size[3] = {lbm->get_Nx(), lbm->get_Ny(), lbm->get_Nz()};
+	const float c[3] = {center.x, center.y, center.z};
+	total[0] = total[1] = total[2] = total[3] = 0.0;
+	for (LBM_Domain* d : lbm->lbm_domain) {
+		double s[4];
+		check(lbmhip_object_sum(d->handle, what, flag_marker, c, size, s));
+		for (int k = 0; k < 4; k++) total[k] += s[k];
+	}
+}
 float3 LBM::object_center_of_mass(const uchar flag_marker) {
-	flags.read_from_device();
-	double sx = 0.0, sy = 0.0, sz = 0.0; ulong cells = 0ull;
-	for (ulong n = 0ull; n < get_N(); n++) if (flags[n] == flag_marker) { const float3 p = position(n); sx += p.x; sy += p.y; sz += p.z; cells++; }
-	return cells ? float3((float)(sx/(double)cells), (float)(sy/(double)cells), (float)(sz/(double)cells)) : float3(0.0f);
+	if (!initialized) flags.write_to_device();
+	double s[4]; object_sums(this, 0, flag_marker, float3(0.0f), s);
+	return s[3] > 0.0 ? float3((float)(s[0]/s[3]), (float)(s[1]/s[3]), (float)(s[2]/s[3])) : float3(0.0f);
 }
 float3 LBM::object_force(const uchar flag_marker) {
 	update_force_field();
-	F.read_from_device(); flags.read_from_device();
-	double sx = 0.0, sy = 0.0, sz = 0.0;
-	for (ulong n = 0ull; n < get_N(); n++) if (flags[n] == flag_marker) { sx += F.x[n]; sy += F.y[n]; sz += F.z[n]; }
-	return float3((float)sx, (float)sy, (float)sz);
+	double s[4]; object_sums(this, 1, flag_marker, float3(0.0f), s);
+	return float3((float)s[0], (float)s[1], (float)s[2]);
 }
 float3 LBM::object_torque(const float3& rotation_center, const uchar flag_marker) {
 	update_force_field();
-	F.read_from_device(); flags.read_from_device();
-	double sx = 0.0, sy = 0.0, sz = 0.0;
-	for (ulong n = 0ull; n < get_N(); n++) if (flags[n] == flag_marker) {
-		const float3 t = cross(position(n)-rotation_center, float3(F.x[n], F.y[n], F.z[n]));
-		sx += t.x; sy += t.y; sz += t.z;
-	}
-	return float3((float)sx, (float)sy, (float)sz);
+	double s[4]; object_sums(this, 2, flag_marker, rotation_center, s);
+	return float3((float)s[0], (float)s[1], (float)s[2]);
 }
 #endif
 #ifdef MOVING_BOUNDARIES

@@ -42,5 +42,17 @@ public:
 	float f_from_u_Poiseuille_2D(const float u, const float rho, const float nu, const float R) const { return 2.0f*u*rho*nu/sq(R); }
 	float f_from_u_Poiseuille_3D(const float u, const float rho, const float nu, const float R) const { return 4.0f*u*rho*nu/sq(R); }
 	float F_Stokes(const float rho, const float u, const float nu, const float R) const { return 6.0f*pif*rho*nu*R*u; }
+	// creeping flow of far-field velocity u0 past a fixed sphere of radius R at the origin (FluidX3D-master/src/units.hpp:125-132):
+	// u = u0 - (3R/4)(u0/r + x (u0.x)/r^3) - (R^3/4)(u0/r^3 - 3 x (u0.x)/r^5), p = -(3/2) rho nu R (u0.x)/r^3, rho = rho0 + 3p
+	float3 u_Stokes(const float3& x, const float3& u0, const float R) const {
+		const float r = length(x);
+		if (r <= R) return float3(0.0f);
+		const float ux = dot(u0, x), r3 = r*r*r, r5 = r3*r*r, R3 = R*R*R;
+		return u0-(u0/r+x*(ux/r3))*(0.75f*R)-(u0/r3-x*(3.0f*ux/r5))*(0.25f*R3);
+	}
+	float rho_Stokes(const float3& x, const float3& u0, const float R, const float rho, const float nu) const {
+		const float r = length(x);
+		return r > R ? rho-4.5f*rho*nu*R*dot(u0, x)/(r*r*r) : rho;
+	}
 };
 extern Units units; // defined in lbm.cpp (FluidX3D-master/src/lbm.cpp:3)

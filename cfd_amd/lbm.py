@@ -334,6 +334,31 @@ class LBM:
             self.t_last_force_field = self.t
         self.sync()
 
+    # ---- LBM::object_center_of_mass / object_force / object_torque (lbm.cpp:1509-1554)
+    def _object_sum(self, what, flag_marker, center=(0.0, 0.0, 0.0)):
+        size = (C.c_uint32 * 3)(*self.N)
+        c = (C.c_float * 3)(*[float(v) for v in center])
+        total = np.zeros(4, dtype=np.float64)
+        for dom in self.domains:
+            s = (C.c_double * 4)()
+            check(self._L.lbmhip_object_sum(dom.h, what, C.c_uint8(flag_marker), c, size, s))
+            total += np.array(s[:])
+        return total
+
+    def object_center_of_mass(self, flag_marker=TYPE_S):
+        if not self.initialized:
+            self.write_to_device(("flags",))
+        s = self._object_sum(0, flag_marker)
+        return tuple(s[:3] / s[3]) if s[3] > 0 else (0.0, 0.0, 0.0)
+
+    def object_force(self, flag_marker=TYPE_S):
+        self.update_force_field()
+        return tuple(self._object_sum(1, flag_marker)[:3])
+
+    def object_torque(self, rotation_center, flag_marker=TYPE_S):
+        self.update_force_field()
+        return tuple(self._object_sum(2, flag_marker, rotation_center)[:3])
+
     def reset(self):
         self.initialized = False
 

@@ -137,6 +137,19 @@ int lbmhip_voxelize_mesh(lbmhip_domain* domain, uint32_t direction, uint64_t t, 
                          const float* rotational_velocity);
 int lbmhip_unvoxelize_mesh(lbmhip_domain* domain, uint8_t flag, const float* bounding_box);
 
+/* ---- sums over the cells whose flags EQUAL flag_marker: kernels object_center_of_mass / object_force / object_torque
+ * (kernel.cpp:1929-1987) and LBM_Domain::enqueue_object_* (lbm.cpp:266-303).  what: 0 = positions (sums[0..2]) and cell
+ * count (sums[3]), 1 = boundary force F, 2 = torque (position - center) x F.  force and torque use the F field as it
+ * is: call lbmhip_update_force_field first.  Complete when the call returns.
+ * global_size == NULL: the reference kernel's definition for this one domain - every cell of the array, halo layers
+ * included, positions from the centre of the domain's own box (kernel.cpp:834-836).
+ * global_size != NULL: halo layers are left to the domain that owns them and positions are measured from the centre of
+ * the global box of global_size cells (lbm.hpp:501-503), so that adding the sums of all domains (lbm.cpp:1509-1554) gives
+ * the object's true total; with one domain both definitions coincide.
+ * The reference adds group sums with float atomics whose order is not fixed; here partial sums are added in a fixed order
+ * in double, so the result is reproducible and agrees with the reference to float rounding of the summation. */
+int lbmhip_object_sum(lbmhip_domain* domain, int what, uint8_t flag_marker, const float* center, const uint32_t* global_size, double* sums);
+
 /* ---- timing on the handle's stream (the reference only has a host clock, lbm.cpp:1481-1483) */
 int lbmhip_timer_start(lbmhip_domain* domain);
 int lbmhip_timer_stop(lbmhip_domain* domain, float* milliseconds); /* waits for the stream */

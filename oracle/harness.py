@@ -73,6 +73,11 @@ class PortEngine:
     def update_moving_boundaries(self, u, flags):
         self.lib.oracle_update_moving_boundaries(self.c, _p(u), _p(flags))
 
+    def object_sum(self, what, F, flags, marker, center=(0.0, 0.0, 0.0)):
+        out = np.zeros(4, dtype=np.float32)
+        self.lib.oracle_object_sum(self.c, int(what), _p(F), _p(flags), C.c_uint8(marker), C.c_float(center[0]), C.c_float(center[1]), C.c_float(center[2]), _p(out))
+        return out
+
     def voxelize_mesh(self, O, direction, fi, u, flags, t, flag, p0, p1, p2, params):
         off = (C.c_int * 3)(*O)
         self.lib.oracle_voxelize_mesh(self.c, off, C.c_uint32(direction), _p(fi), _p(u), _p(flags), C.c_uint64(t), C.c_uint8(flag), _p(p0), _p(p1), _p(p2), _p(params))
@@ -118,6 +123,11 @@ class RefEngine:
 
     def update_moving_boundaries(self, u, flags):
         assert self.lib.ref_update_moving_boundaries(_p(u), _p(flags), 1) == 0
+
+    def object_sum(self, what, F, flags, marker, center=(0.0, 0.0, 0.0)):
+        out = np.zeros(4, dtype=np.float32)
+        assert self.lib.ref_object_sum(int(what), _p(F), _p(flags), C.c_uint8(marker), C.c_float(center[0]), C.c_float(center[1]), C.c_float(center[2]), _p(out)) == 0
+        return out
 
     def voxelize_mesh(self, O, direction, fi, u, flags, t, flag, p0, p1, p2, params):
         self.lib.ref_voxelize_mesh(C.c_uint32(direction), _p(fi), _p(u), _p(flags), C.c_uint64(t), C.c_uint8(flag), _p(p0), _p(p1), _p(p2), _p(params))
@@ -278,3 +288,27 @@ class OracleLBM:
     def update_force_field(self):
         for dom in self.domains:
             dom.engine.update_force_field(dom.fi, dom.flags, self.t, dom.F)
+
+    # ---- FluidX3D-master/src/lbm.cpp:266-303, 1509-1554: per-domain kernel sums, added in float on the host
+    def _object_sum(self, what, marker, center=(0.0, 0.0, 0.0)):
+        total = np.zeros(3, dtype=np.float32)
+        cells = 0
+        for dom in self.domains:
+            s = dom.engine.object_sum(what, dom.F, dom.flags, marker, center)
+            total = (total + s[:3]).astype(np.float32)
+            cells += int(s[3:4].view(np.uint32)[0])
+        return total, cells
+
+    def object_center_of_mass(self, marker=TYPE_S):
+        if not self.initialized:
+            self._scatter()
+        total, cells = self._object_sum(0, marker)
+        return (total / np.float32(cells)).astype(np.float32)
+
+    def object_force(self, marker=TYPE_S):
+        self.update_force_field()
+        return self._object_sum(1, marker)[0]
+
+    def object_torque(self, center, marker=TYPE_S):
+        self.update_force_field()
+        return self._object_sum(2, marker, center)[0]

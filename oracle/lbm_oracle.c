@@ -591,6 +591,51 @@ void oracle_unvoxelize_mesh(const oracle_cfg* cfg, const int* O, uint8_t* flags,
 }
 
 /* storage-format converters exposed so tests can pin them against numpy float16 and the reference */
+/* ----------------------------------------------------------------------------------------------
+ * Object sums: object_center_of_mass / object_force / object_torque (kernel.cpp:1929-1987) for ONE domain, as
+ * the kernels define them: every cell of the domain's array whose flags equal `marker` (halo layers included),
+ * positions measured from the centre of this domain's own box (kernel.cpp:834-836).  Work-groups of 64 cells
+ * reduce by the pairwise tree of kernel.cpp:1938-1944; group sums are added in ascending group order (on a GPU
+ * the atomics of kernel.cpp:1948-1951 land in no fixed order, so the last bits of the reference's own result
+ * vary from run to run; ascending order is what oracle/_ref produces).  what: 0 positions, sum[3] = cell count
+ * as integer bits (lbm.cpp:1522); 1 force; 2 torque about (cx, cy, cz).
+ * ---------------------------------------------------------------------------------------------- */
+void oracle_object_sum(const oracle_cfg* cfg, int what, const float* F, const uint8_t* flags, uint8_t marker, float cx, float cy, float cz, float* sum) {
+	const uint64_t N = cells(cfg), groups = (N+63u)/64u;
+	uint32_t total_cells = 0u;
+	sum[0] = sum[1] = sum[2] = sum[3] = 0.0f;
+	for (uint64_t g = 0u; g < groups; g++) {
+		vec3 cache[64];
+		uint32_t count[64];
+		for (uint32_t lid = 0u; lid < 64u; lid++) {
+			const uint64_t n = g*64u+lid;
+			cache[lid] = v3(0.0f, 0.0f, 0.0f);
+			count[lid] = 0u;
+			if (n >= N || flags[n] != marker) continue;
+			uint32_t x, y, z;
+			coordinates(cfg, n, &x, &y, &z);
+			const vec3 p = v3((float)x+0.5f-0.5f*(float)cfg->Nx, (float)y+0.5f-0.5f*(float)cfg->Ny, (float)z+0.5f-0.5f*(float)cfg->Nz);
+			count[lid] = 1u;
+			if (what == 0) cache[lid] = p;
+			else {
+				const vec3 f = v3(F[n], F[N+n], F[2u*N+n]);
+				cache[lid] = what == 1 ? f : vcross(vsub(p, v3(cx, cy, cz)), f);
+			}
+		}
+		for (uint32_t s = 1u; s < 64u; s *= 2u) {
+			for (uint32_t lid = 0u; lid < 64u; lid += 2u*s) { cache[lid] = vadd(cache[lid], cache[lid+s]); count[lid] += count[lid+s]; }
+		}
+		if (what == 0) {
+			if (count[0] > 0u) { sum[0] += cache[0].x; sum[1] += cache[0].y; sum[2] += cache[0].z; total_cells += count[0]; }
+		} else {
+			if (cache[0].x != 0.0f) sum[0] += cache[0].x;
+			if (cache[0].y != 0.0f) sum[1] += cache[0].y;
+			if (cache[0].z != 0.0f) sum[2] += cache[0].z;
+		}
+	}
+	if (what == 0) memcpy(&sum[3], &total_cells, 4u);
+}
+
 float oracle_half_to_float(uint16_t h) { return half_to_float(h); }
 uint16_t oracle_float_to_half(float x) { return float_to_half_rte(x); }
 float oracle_fp16c_to_float(uint16_t h) { return fp16c_to_float(h); }

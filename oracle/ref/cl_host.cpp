@@ -3,13 +3,16 @@
 //  (1) the OpenCL C language built-ins those kernels call, defined as the OpenCL C specification
 //      describes them (single-precision, round-to-nearest);
 //  (2) a driver that runs a 1-D NDRange by looping the global id, optionally split over std::threads
-//      (cells are independent within one kernel launch, FluidX3D-master/src/kernel.cpp:1481-1485).
+//      (cells are independent within one kernel launch, FluidX3D-master/src/kernel.cpp:1481-1485);
+//      kernels that call barrier() (the object_* reductions, kernel.cpp:1929-1987) run one work-group at a
+//      time on 64 threads that meet at a pthread barrier, groups in ascending order.
 // The kernels' signatures are those of FluidX3D-master/src/kernel.cpp:1364, 1470, 1812, 1897, 1911,
 // 2148, 2154, 2175, 2181, 2212, 2218.  Grid size, velocity set and feature set are baked into the
 // kernel object; the REF_* macros given on the command line mirror them for this file.
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <pthread.h>
 #include <thread>
 #include <vector>
 
@@ -44,7 +47,8 @@ float cl_atomic_xchg(volatile float*, float) BUILTIN("_Z11atomic_xchgPU8CLglobal
 
 ulong cl_get_global_id(uint) { return tl_global_id; }
 ulong cl_get_local_id(uint) { return tl_global_id % 64ul; }
-void cl_barrier(uint) {} // only reached from the object_* reductions, which this driver never launches
+static pthread_barrier_t group_barrier; // the 64 work-items of the one work-group in flight (ndrange_groups)
+void cl_barrier(uint) { pthread_barrier_wait(&group_barrier); }
 float cl_fma(float a, float b, float c) { return std::fmaf(a, b, c); }
 uint cl_min(uint a, uint b) { return a < b ? a : b; }
 float cl_acos(float x) { return std::acos(x); }
@@ -95,6 +99,11 @@ void transfer__insert_F(uint direction, ulong t, const float* p, const float* m,
 #ifdef REF_MOVING_BOUNDARIES
 void update_moving_boundaries(const float* u, uchar* flags);
 #endif
+#ifdef REF_FORCE_FIELD
+void object_center_of_mass(const uchar* flags, uchar flag_marker, volatile float* object_sum);
+void object_force(const float* F, const uchar* flags, uchar flag_marker, volatile float* object_sum);
+void object_torque(const float* F, const uchar* flags, uchar flag_marker, float cx, float cy, float cz, volatile float* object_sum);
+#endif
 void voxelize_mesh(uint direction, fpxx* fi, float* u, uchar* flags, ulong t, uchar flag, const float* p0, const float* p1, const float* p2, const float* bbu);
 void unvoxelize_mesh(uchar* flags, uchar flag, float x0, float y0, float z0, float x1, float y1, float z1);
 void transfer_extract_fi(uint direction, ulong t, fpxx* p, fpxx* m, const fpxx* fi);
@@ -116,6 +125,26 @@ template <typename K> static void ndrange(const ulong range, const int threads, 
 		pool.emplace_back([=]() { for (ulong n = a; n < b; n++) { tl_global_id = n; kernel(); } });
 	}
 	for (auto& th : pool) th.join();
+}
+
+// Work-groups of 64 one after the other (the kernels' local arrays are one static array each on this target), the 64
+// work-items of a group on 64 threads so that barrier() has OpenCL's meaning.  Group sums therefore reach the kernels'
+// atomics in ascending group order, which makes the float result reproducible.
+template <typename K> static void ndrange_groups(const ulong range, K kernel) {
+	const ulong groups = (range + 63ul) / 64ul;
+	pthread_barrier_init(&group_barrier, nullptr, 64u);
+	std::vector<std::thread> pool;
+	for (ulong lid = 0ul; lid < 64ul; lid++) {
+		pool.emplace_back([=]() {
+			for (ulong g = 0ul; g < groups; g++) {
+				tl_global_id = g * 64ul + lid;
+				kernel();
+				pthread_barrier_wait(&group_barrier); // the group's atomics are done before the next group reuses local memory
+			}
+		});
+	}
+	for (auto& th : pool) th.join();
+	pthread_barrier_destroy(&group_barrier);
 }
 
 static const ulong N = (ulong)REF_NX * (ulong)REF_NY * (ulong)REF_NZ;
@@ -186,6 +215,19 @@ API int ref_update_moving_boundaries(const float* u, uchar* flags, int threads) 
 	return 0;
 #else
 	(void)u; (void)flags; (void)threads;
+	return -1;
+#endif
+}
+// what: 0 object_center_of_mass (sum[3] holds the cell count as uint bits), 1 object_force, 2 object_torque
+API int ref_object_sum(int what, const float* F, const uchar* flags, uchar flag_marker, float cx, float cy, float cz, float* sum) {
+#ifdef REF_FORCE_FIELD
+	sum[0] = sum[1] = sum[2] = sum[3] = 0.0f; // LBM_Domain::enqueue_object_* reset (FluidX3D-master/src/lbm.cpp:269-271)
+	if (what == 0) ndrange_groups(N, [=]() { object_center_of_mass(flags, flag_marker, sum); });
+	else if (what == 1) ndrange_groups(N, [=]() { object_force(F, flags, flag_marker, sum); });
+	else ndrange_groups(N, [=]() { object_torque(F, flags, flag_marker, cx, cy, cz, sum); });
+	return 0;
+#else
+	(void)what; (void)F; (void)flags; (void)flag_marker; (void)cx; (void)cy; (void)cz; (void)sum;
 	return -1;
 #endif
 }

@@ -8,6 +8,8 @@ Each fixture holds, for one parity case of tests/cases.py after its `steps` time
   sum_*      float64 sums of rho and |u| (size-independent sanity),
   flags      the complete flag lattice (uint8),
   rho_sub, u_sub   every 2nd cell per axis of rho and u (for tolerance-based comparison of the 16-bit formats),
+  pins["object"]  (FORCE_FIELD cases) the object_center_of_mass / object_force / object_torque kernel sums per domain
+                   and the host totals, groups added in ascending order,
 plus the generating configuration.  Only data is stored; no reference source.
 """
 import json
@@ -38,6 +40,14 @@ def summarize(lbm):
     return out
 
 
+OBJECT_CENTER = (1.5, -2.0, 0.5)
+
+
+def object_marker(lbm):
+    """The flag value of the case's solid body: TYPE_S|TYPE_X where the setup marks one, else TYPE_S."""
+    return 65 if (lbm.flags == 65).any() else 1
+
+
 def main():
     out_dir = os.path.dirname(os.path.abspath(__file__))
     for name, case in sorted(CASES.items()):
@@ -51,6 +61,16 @@ def main():
             ref.read_from_device()
         pins = summarize(ref)
         pins["crc_fi"] = [crc(d.fi) for d in ref.domains]
+        if ref.F is not None:  # the object_* reduction kernels, per domain as the kernels define them, and the host totals
+            marker = object_marker(ref)
+            pins["object"] = {"marker": marker, "center": list(OBJECT_CENTER),
+                              "com": [float(v) for v in ref.object_center_of_mass(marker)],
+                              "force": [float(v) for v in ref.object_force(marker)],
+                              "torque": [float(v) for v in ref.object_torque(OBJECT_CENTER, marker)],
+                              "domain_force": [[float(v) for v in d.engine.object_sum(1, d.F, d.flags, marker)[:3]] for d in ref.domains],
+                              "domain_torque": [[float(v) for v in d.engine.object_sum(2, d.F, d.flags, marker, OBJECT_CENTER)[:3]] for d in ref.domains],
+                              "domain_com": [[float(v) for v in d.engine.object_sum(0, d.F, d.flags, marker)[:3]] for d in ref.domains],
+                              "domain_cells": [int(d.engine.object_sum(0, d.F, d.flags, marker)[3:4].view(np.uint32)[0]) for d in ref.domains]}
         meta = {"case": name, "steps": case["steps"], "kw": {k: (list(v) if isinstance(v, tuple) else v) for k, v in kw.items()},
                 "generator": "oracle/_ref (reference OpenCL kernels, clang -x cl, x86-64), tests/golden/make_golden.py"}
         np.savez_compressed(os.path.join(out_dir, name + ".npz"), meta=json.dumps(meta), pins=json.dumps(pins), flags=ref.flags,

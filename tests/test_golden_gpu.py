@@ -29,6 +29,26 @@ def test_hip_reproduces_reference_fixture(gpu, name):
             if k.startswith("crc"):
                 assert v == pins[k], "%s: %s differs from the reference fixture" % (name, k)
         assert [crc(d.download_fi()) for d in lbm.domains] == pins["crc_fi"]
+        if "object" in pins:
+            # object_* reductions.  F is bit-identical (crc_F above); what is left is the ORDER of the float additions, which the
+            # reference leaves to its atomics.  Tolerance: 1e-5 of the sum of magnitudes (cancellation-safe float32 bound).
+            import ctypes as C
+            o = pins["object"]
+            sel = lbm.flags == o["marker"]
+            scale_f = float(np.abs(lbm.F[:, sel]).sum())
+            for d, dom in enumerate(lbm.domains):   # per domain, the kernels' own definition (halo cells included, local positions)
+                s = (C.c_double * 4)()
+                cfd_amd.lbm.check(lbm._L.lbmhip_object_sum(dom.h, 1, C.c_uint8(o["marker"]), None, None, s))
+                assert np.allclose(s[:3], o["domain_force"][d], rtol=0, atol=1e-5 * scale_f + 1e-12), (d, s[:3], o["domain_force"][d])
+                cfd_amd.lbm.check(lbm._L.lbmhip_object_sum(dom.h, 2, C.c_uint8(o["marker"]), (C.c_float * 3)(*o["center"]), None, s))
+                assert np.allclose(s[:3], o["domain_torque"][d], rtol=0, atol=1e-5 * scale_f * max(lbm.N) + 1e-12)
+                cfd_amd.lbm.check(lbm._L.lbmhip_object_sum(dom.h, 0, C.c_uint8(o["marker"]), None, None, s))
+                assert int(s[3]) == o["domain_cells"][d]
+                assert np.allclose(s[:3], o["domain_com"][d], rtol=1e-5, atol=1e-3)
+            if len(lbm.domains) == 1:   # one domain: the host totals of the reference are the same quantity
+                assert np.allclose(lbm.object_force(o["marker"]), o["force"], rtol=0, atol=1e-5 * scale_f)
+                assert np.allclose(lbm.object_torque(tuple(o["center"]), o["marker"]), o["torque"], rtol=0, atol=1e-5 * scale_f * max(lbm.N))
+                assert np.allclose(lbm.object_center_of_mass(o["marker"]), o["com"], rtol=1e-5, atol=1e-4)
 
 
 def _run(N, steps, shift=(0, 0, 0), **kw):

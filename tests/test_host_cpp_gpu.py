@@ -102,3 +102,15 @@ def test_fluid_wrapper_as_solver_py_binds_it(gpu, tmp_path):
         assert np.array_equal(vx.reshape(res, res, res).view(np.uint32), lbm.u[0].view(np.uint32))
         assert np.array_equal(vz.reshape(res, res, res).view(np.uint32), lbm.u[2].view(np.uint32))
     assert vz.max() > 1e-3 and np.isfinite(vx).all()
+
+
+def test_stokes_drag_example_object_sums(gpu):
+    """object_force / object_torque / object_center_of_mass through the C++ host: drag on a staircase sphere in creeping
+    flow is within 12 % of Stokes' law (R = 16 cells), points along the flow, and has no torque."""
+    out = run_example("stokes_drag")
+    w = [l for l in out.splitlines() if l.startswith("force ")][0].split()
+    force, stokes, torque, com = [float(v) for v in w[1:4]], float(w[5]), [float(v) for v in w[7:10]], [float(v) for v in w[11:14]]
+    assert force[0] < 0 and abs(abs(force[0]) - stokes) / stokes < 0.12
+    assert abs(force[1]) < 1e-5 * stokes and abs(force[2]) < 1e-5 * stokes
+    assert max(abs(t) for t in torque) < 1e-4 * stokes * 16
+    assert max(abs(c) for c in com) < 1e-3

@@ -44,6 +44,15 @@ def test_port_reproduces_reference_fixture(name):
     assert [crc(d.fi) for d in lbm.domains] == pins["crc_fi"]
     assert np.array_equal(lbm.rho[::2, ::2, ::2], z["rho_sub"]) and np.array_equal(lbm.u[:, ::2, ::2, ::2], z["u_sub"])
     assert abs(got["sum_rho"] - pins["sum_rho"]) == 0.0
+    if "object" in pins:  # the object_* reduction kernels: same summation order as oracle/_ref, so the floats are identical
+        o = pins["object"]
+        f32 = lambda v: np.asarray(v, dtype=np.float32)
+        assert np.array_equal(lbm.object_center_of_mass(o["marker"]), f32(o["com"]))
+        assert np.array_equal(lbm.object_force(o["marker"]), f32(o["force"]))
+        assert np.array_equal(lbm.object_torque(tuple(o["center"]), o["marker"]), f32(o["torque"]))
+        for d, dom in enumerate(lbm.domains):
+            assert np.array_equal(dom.engine.object_sum(1, dom.F, dom.flags, o["marker"])[:3], f32(o["domain_force"][d]))
+        assert sum(o["domain_cells"]) > 100 and np.abs(f32(o["force"])).max() > 0
 
 
 @pytest.mark.parametrize("name", ["tgv32_fp32_srt", "all_fp16s_trt_2dom", "q27_fp16c_force", "q9_fp32_srt"])

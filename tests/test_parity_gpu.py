@@ -82,3 +82,34 @@ def test_overlap_matches_plain_exchange(gpu):
             assert np.array_equal(da.download_fi(), db.download_fi())
     finally:
         a.close(); b.close()
+
+
+def test_object_sums_match_host_definition(gpu):
+    """object_center_of_mass / object_force / object_torque: sums over the cells flagged TYPE_S|TYPE_X.  The reference
+    adds group sums with float atomics in arbitrary order, so the comparison is against the plain definition in double,
+    for one domain and for several (where halo cells must not be counted twice)."""
+    case = CASES["q27_fp16c_force"]
+    for D in ((1, 1, 1), (2, 1, 2)):
+        kw = dict(case["kw"], D=D)
+        with cfd_amd.LBM(**kw) as lbm:
+            case["setup"](lbm)
+            lbm.run(30)
+            marker = 1 | 64
+            force = np.array(lbm.object_force(marker))
+            torque = np.array(lbm.object_torque((1.5, -2.0, 0.5), marker))
+            com = np.array(lbm.object_center_of_mass(marker))
+            lbm.read_from_device()
+            sel = lbm.flags == marker
+            assert sel.sum() > 500
+            Nx, Ny, Nz = lbm.N
+            z, y, x = np.meshgrid(np.arange(Nz), np.arange(Ny), np.arange(Nx), indexing="ij")
+            pos = np.stack([x + 0.5 - 0.5 * Nx, y + 0.5 - 0.5 * Ny, z + 0.5 - 0.5 * Nz]).astype(np.float64)
+            F = lbm.F.astype(np.float64)
+            want_force = F[:, sel].sum(axis=1)
+            r = pos[:, sel] - np.array([1.5, -2.0, 0.5])[:, None]
+            want_torque = np.cross(r.T, F[:, sel].T).sum(axis=0)
+            want_com = pos[:, sel].mean(axis=1)
+            assert np.abs(want_force).max() > 1e-4
+            assert np.allclose(force, want_force, rtol=1e-4, atol=1e-7)
+            assert np.allclose(torque, want_torque, rtol=1e-4, atol=1e-6)
+            assert np.allclose(com, want_com, rtol=1e-5, atol=1e-4)
