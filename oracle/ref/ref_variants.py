@@ -24,8 +24,9 @@ def case_config(tag, kw):
 
 
 def all_configs():
-    from tests.cases import CASES
+    from tests.cases import CASES, LONG_CASES
     cfgs = [case_config(name, c["kw"]) for name, c in sorted(CASES.items())]
+    cfgs += [case_config(name, c["kw"]) for name, c in sorted(LONG_CASES.items())]
     from tests.voxel_cases import VOXEL_CASES
     for name, c in sorted(VOXEL_CASES.items()):  # the voxelizer reads the baked-in domain offset: one library per domain
         D = c["D"]
@@ -34,7 +35,6 @@ def all_configs():
             cfg["O"] = decomposition.domain_offset(d, decomposition.rounded_size(c["N"], D), D)
             cfgs.append(cfg)
     cfgs.append(case_config("bench_tgv256", dict(N=(256, 256, 256), nu=0.01)))
-    cfgs.append(case_config("cavity128", dict(N=(128, 128, 128), nu=0.0126, features=("MOVING_BOUNDARIES",))))
     return cfgs
 
 

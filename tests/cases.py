@@ -47,3 +47,17 @@ CASES = {
     "q15_fp32_srt": dict(kw=dict(N=(24, 24, 24), nu=0.02, Q=15, D=(2, 1, 1)), setup=setups.taylor_green, steps=30),
     "q9_fp32_srt": dict(kw=dict(N=(48, 32, 1), nu=0.02, Q=9), setup=_tgv2d, steps=40),
 }
+
+
+# Long runs: the benchmark configurations at sizes the compiled reference kernels finish in about a minute on all cores,
+# over the 1000 steps the tolerance is quoted for.  name -> dict(kw, setup, steps, tolerance = relative L2 bound on rho and u)
+LONG_CASES = {
+    "long_cavity128_fp32": dict(kw=dict(N=(128, 128, 128), nu=0.0126, features=("MOVING_BOUNDARIES",)), setup=setups.lid_cavity, steps=1000, tolerance=1e-5),
+    "long_tgv64_fp32": dict(kw=dict(N=(64, 64, 64), nu=0.01), setup=setups.taylor_green, steps=1000, tolerance=1e-5),
+    "long_tgv128_fp32": dict(kw=dict(N=(128, 128, 128), nu=0.01), setup=setups.taylor_green, steps=1000, tolerance=1e-5),
+    "long_tgv128_fp16s": dict(kw=dict(N=(128, 128, 128), nu=0.01, storage="FP16S"), setup=setups.taylor_green, steps=1000, tolerance=1e-3),
+    "long_channel_trt_sgs_2slab": dict(kw=dict(N=(96, 64, 64), nu=0.005, D=(1, 1, 2), collision="TRT", features=("VOLUME_FORCE", "SUBGRID"), f=(2e-4, 0.0, 0.0)),
+                                       setup=_channel_setup, steps=1000, tolerance=1e-5),
+    "long_q27_fp16c_force_4slab": dict(kw=dict(N=(48, 48, 96), nu=0.02, Q=27, D=(1, 1, 4), storage="FP16C", features=("VOLUME_FORCE", "FORCE_FIELD", "EQUILIBRIUM_BOUNDARIES")),
+                                       setup=_sphere_setup, steps=1000, tolerance=1e-3),
+}

@@ -7,7 +7,7 @@ Each fixture holds, for one parity case of tests/cases.py after its `steps` time
   crc_*      CRC-32 of the raw bytes of flags, rho, u, (F,) and of every domain's DDF buffer (bit-exact pins),
   sum_*      float64 sums of rho and |u| (size-independent sanity),
   flags      the complete flag lattice (uint8),
-  rho_sub, u_sub   every 2nd cell per axis of rho and u (for tolerance-based comparison of the 16-bit formats),
+  rho_sub, u_sub   every 2nd (long cases: 4th) cell per axis of rho and u, for the tolerance-based comparison,
   pins["object"]  (FORCE_FIELD cases) the object_center_of_mass / object_force / object_torque kernel sums per domain
                    and the host totals, groups added in ascending order,
 plus the generating configuration.  Only data is stored; no reference source.
@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 
 from oracle import harness as H  # noqa: E402
-from tests.cases import CASES  # noqa: E402
+from tests.cases import CASES, LONG_CASES  # noqa: E402
 from tests.voxel_cases import VOXEL_CASES, voxelize_with_engine  # noqa: E402
 
 
@@ -50,11 +50,14 @@ def object_marker(lbm):
 
 def main():
     out_dir = os.path.dirname(os.path.abspath(__file__))
-    for name, case in sorted(CASES.items()):
+    only = sys.argv[1:]
+    for name, case in sorted(list(CASES.items()) + list(LONG_CASES.items())):
+        if only and not any(name.startswith(o) for o in only):
+            continue
         kw = dict(case["kw"])
         ref = H.OracleLBM(engine_factory=lambda local, D, n=name: H.RefEngine(n), **kw)
         case["setup"](ref)
-        ref.run(case["steps"])
+        ref.run(case["steps"], threads=os.cpu_count() if name in LONG_CASES else 1)  # cells are independent within a step
         ref.read_from_device()
         if ref.F is not None:
             ref.update_force_field()
@@ -73,11 +76,14 @@ def main():
                               "domain_cells": [int(d.engine.object_sum(0, d.F, d.flags, marker)[3:4].view(np.uint32)[0]) for d in ref.domains]}
         meta = {"case": name, "steps": case["steps"], "kw": {k: (list(v) if isinstance(v, tuple) else v) for k, v in kw.items()},
                 "generator": "oracle/_ref (reference OpenCL kernels, clang -x cl, x86-64), tests/golden/make_golden.py"}
+        k = 4 if name in LONG_CASES else 2  # sub-sampling stride of the stored rho/u
         np.savez_compressed(os.path.join(out_dir, name + ".npz"), meta=json.dumps(meta), pins=json.dumps(pins), flags=ref.flags,
-                            rho_sub=ref.rho[::2, ::2, ::2], u_sub=ref.u[:, ::2, ::2, ::2])
+                            rho_sub=ref.rho[::k, ::k, ::k], u_sub=ref.u[:, ::k, ::k, ::k])
         print(name, pins["crc_rho"], pins["crc_u"], "%.6f" % pins["sum_rho"])
     # voxelizer fixtures: flags (complete) and the CRC of u from the reference's voxelize_mesh kernel
     for name, case in sorted(VOXEL_CASES.items()):
+        if only and not any(("voxel_" + name).startswith(o) for o in only):
+            continue
         flags, u = voxelize_with_engine(case, lambda local, D, d, n=name: H.RefEngine("voxel_%s_d%d" % (n, d)))
         np.savez_compressed(os.path.join(out_dir, "voxel_" + name + ".npz"), flags=flags, crc_u=np.uint32(crc(u)),
                             meta=json.dumps({"case": name, "generator": "oracle/_ref voxelize_mesh, tests/golden/make_golden.py"}))

@@ -47,7 +47,7 @@ template <int V> struct Vec { typedef float type __attribute__((ext_vector_type(
 template <> struct Vec<1> { typedef float type; };
 
 // MODE 0: all streams aligned at the own cell. MODE 1: odd streams of each pair at the neighbour (x+cx, y+cy, z+cz) like D3Q19.
-template <int V, int MODE, bool NT, bool NTS = NT> __global__ __launch_bounds__(1024) void k_rmw(float* fi, size_t N, unsigned Nx, unsigned Ny, unsigned Nz, unsigned xchunks, float s) {
+template <int V, int MODE, bool NT, bool NTS = NT> __global__ __launch_bounds__(1024) void k_rmw(float* fi, float* fo, size_t N, unsigned Nx, unsigned Ny, unsigned Nz, unsigned xchunks, float s) {
 	typedef typename Vec<V>::type vec;
 	const unsigned chunk = blockIdx.x%xchunks, r = blockIdx.x/xchunks, z = r/Ny, y = r%Ny;
 	const unsigned x = (chunk*blockDim.x+threadIdx.x)*V;
@@ -72,7 +72,7 @@ template <int V, int MODE, bool NT, bool NTS = NT> __global__ __launch_bounds__(
 		f[1+2*k] = ld(fi+(size_t)(2+2*k)*N+row0, x, true);
 		if (MODE == 0) f[2+2*k] = ld(fi+(size_t)(1+2*k)*N+row0, x, true);
 		else {
-			const float* p = fi+(size_t)(1+2*k)*N+((size_t)zq[cz[k] == 0 ? 0 : cz[k] > 0 ? 1 : 2]*Ny+yq[cy[k] == 0 ? 0 : cy[k] > 0 ? 1 : 2])*Nx;
+			const float* p = fo+(size_t)(1+2*k)*N+((size_t)zq[cz[k] == 0 ? 0 : cz[k] > 0 ? 1 : 2]*Ny+yq[cy[k] == 0 ? 0 : cy[k] > 0 ? 1 : 2])*Nx;
 			if (cx[k] == 0) f[2+2*k] = ld(p, x, true);
 			else if (x+V < Nx) f[2+2*k] = ld(p, x+1, false);
 			else { vec t; for (int v = 0; v < V; v++) { unsigned xn = x+v+1; float e = p[xn == Nx ? 0 : xn]; if constexpr (V == 1) t = e; else t[v] = e; } f[2+2*k] = t; }
@@ -83,16 +83,74 @@ template <int V, int MODE, bool NT, bool NTS = NT> __global__ __launch_bounds__(
 	for (int i = 1; i < 19; i++) sum += f[i];
 #pragma unroll
 	for (int i = 0; i < 19; i++) f[i] = f[i]*s+sum*1e-3f;
-	st(fi+row0, x, true, f[0]);
+	st(fo+row0, x, true, f[0]);
 #pragma unroll
 	for (int k = 0; k < 9; k++) {
-		st(fi+(size_t)(2+2*k)*N+row0, x, true, f[2+2*k]);
-		if (MODE == 0) st(fi+(size_t)(1+2*k)*N+row0, x, true, f[1+2*k]);
+		st(fo+(size_t)(2+2*k)*N+row0, x, true, f[2+2*k]);
+		if (MODE == 0) st(fo+(size_t)(1+2*k)*N+row0, x, true, f[1+2*k]);
 		else {
-			float* p = fi+(size_t)(1+2*k)*N+((size_t)zq[cz[k] == 0 ? 0 : cz[k] > 0 ? 1 : 2]*Ny+yq[cy[k] == 0 ? 0 : cy[k] > 0 ? 1 : 2])*Nx;
+			float* p = fo+(size_t)(1+2*k)*N+((size_t)zq[cz[k] == 0 ? 0 : cz[k] > 0 ? 1 : 2]*Ny+yq[cy[k] == 0 ? 0 : cy[k] > 0 ? 1 : 2])*Nx;
 			if (cx[k] == 0) st(p, x, true, f[1+2*k]);
 			else if (x+V < Nx) st(p, x+1, false, f[1+2*k]);
 			else { for (int v = 0; v < V; v++) { unsigned xn = x+v+1; float e; if constexpr (V == 1) e = f[1+2*k]; else e = f[1+2*k][v]; p[xn == Nx ? 0 : xn] = e; } }
+		}
+	}
+}
+
+
+// 16-bit variant of k_rmw MODE 1: Q19 streams of ushort, V cells per lane; SHIFT 0: shifted slots element by element,
+// SHIFT 1: shifted slots rebuilt from the lane's own aligned vector and the next lane's first element (DPP/shuffle),
+// so that every access is an aligned V*2-byte vector.  WORK extra dependent FMAs per value emulate the collision cost.
+template <int V, int SHIFT, int WORK> __global__ __launch_bounds__(256) void k_rmw16(unsigned short* fi, size_t N, unsigned Nx, unsigned Ny, unsigned Nz, unsigned xchunks, float s) {
+	typedef unsigned short vec __attribute__((ext_vector_type(V)));
+	const unsigned chunk = blockIdx.x%xchunks, r = blockIdx.x/xchunks, z = r/Ny, y = r%Ny;
+	const unsigned x = (chunk*blockDim.x+threadIdx.x)*V;
+	if (x >= Nx) return;
+	const unsigned yq[3] = {y, y+1 == Ny ? 0 : y+1, y == 0 ? Ny-1 : y-1}, zq[3] = {z, z+1 == Nz ? 0 : z+1, z == 0 ? Nz-1 : z-1};
+	const size_t row0 = ((size_t)z*Ny+y)*Nx;
+	constexpr int cx[9] = {1,0,0,1,1,0,1,1,0}, cy[9] = {0,1,0,1,0,1,-1,0,1}, cz[9] = {0,0,1,0,1,1,0,-1,-1};
+	vec f[19];
+	f[0] = *(const vec*)(fi+row0+x);
+#pragma unroll
+	for (int k = 0; k < 9; k++) {
+		f[1+2*k] = *(const vec*)(fi+(size_t)(2+2*k)*N+row0+x);
+		const unsigned short* p = fi+(size_t)(1+2*k)*N+((size_t)zq[cz[k] == 0 ? 0 : cz[k] > 0 ? 1 : 2]*Ny+yq[cy[k] == 0 ? 0 : cy[k] > 0 ? 1 : 2])*Nx;
+		if (cx[k] == 0) f[2+2*k] = *(const vec*)(p+x);
+		else if (SHIFT == 0) { vec t; for (int v = 0; v < V; v++) { const unsigned xn = x+v+1; t[v] = p[xn == Nx ? 0 : xn]; } f[2+2*k] = t; }
+		else {
+			const vec own = *(const vec*)(p+x);
+			unsigned first = own[0];
+			unsigned nxt = __shfl_down(first, 1);                       // first element of the next lane's vector
+			if ((threadIdx.x&63u) == 63u || x+V >= Nx) { const unsigned xn = x+V; nxt = p[xn >= Nx ? 0 : xn]; }
+			vec t; for (int v = 0; v+1 < V; v++) t[v] = own[v+1]; t[V-1] = (unsigned short)nxt;
+			f[2+2*k] = t;
+		}
+	}
+	float g[19][V];
+	float sum[V];
+#pragma unroll
+	for (int v = 0; v < V; v++) { sum[v] = 0.0f; for (int i = 0; i < 19; i++) { g[i][v] = (float)f[i][v]; sum[v] += g[i][v]; } }
+#pragma unroll
+	for (int v = 0; v < V; v++) for (int i = 0; i < 19; i++) { float t = g[i][v]*s+sum[v]*1e-3f; for (int w = 0; w < WORK; w++) t = fmaf(t, s, 1e-3f); g[i][v] = t; }
+	vec o[19];
+#pragma unroll
+	for (int i = 0; i < 19; i++) for (int v = 0; v < V; v++) o[i][v] = (unsigned short)g[i][v];
+	*(vec*)(fi+row0+x) = o[0];
+#pragma unroll
+	for (int k = 0; k < 9; k++) {
+		*(vec*)(fi+(size_t)(2+2*k)*N+row0+x) = o[2+2*k];
+		unsigned short* p = fi+(size_t)(1+2*k)*N+((size_t)zq[cz[k] == 0 ? 0 : cz[k] > 0 ? 1 : 2]*Ny+yq[cy[k] == 0 ? 0 : cy[k] > 0 ? 1 : 2])*Nx;
+		const vec t = o[1+2*k];
+		if (cx[k] == 0) *(vec*)(p+x) = t;
+		else if (SHIFT == 0) { for (int v = 0; v < V; v++) { const unsigned xn = x+v+1; p[xn == Nx ? 0 : xn] = t[v]; } }
+		else {
+			// the aligned vector at x holds the cells x..x+V-1: element 0 comes from the previous lane's last value
+			unsigned last = t[V-1];
+			unsigned prev = __shfl_up(last, 1);
+			const bool edge = (threadIdx.x&63u) == 0u;
+			vec w; w[0] = (unsigned short)prev; for (int v = 1; v < V; v++) w[v] = t[v-1];
+			if (!edge) *(vec*)(p+x) = w; else { for (int v = 1; v < V; v++) p[x+v] = w[v]; }
+			if ((threadIdx.x&63u) == 63u || x+V >= Nx) { const unsigned xn = x+V; p[xn >= Nx ? 0 : xn] = t[V-1]; }
 		}
 	}
 }
@@ -109,14 +167,16 @@ template <class F> float time_ms(F launch, int reps) {
 template <int V, int MODE, bool NT> void run(float* fi, size_t N, unsigned n, unsigned block, size_t pad, unsigned blocks_per_cu = 0) {
 	const unsigned lanes = n/V, b = block > lanes ? lanes : block, xchunks = (lanes+b-1)/b;
 	const unsigned lds = blocks_per_cu ? (160u*1024u/blocks_per_cu)&~255u : 0u; // dynamic LDS only throttles residency
-	const float ms = time_ms([&]() { hipLaunchKernelGGL((k_rmw<V, MODE, NT>), dim3(xchunks*n*n), dim3(b), lds, 0, fi, N+pad, n, n, n, xchunks, 0.999f); }, 10);
+	const float ms = time_ms([&]() { hipLaunchKernelGGL((k_rmw<V, MODE, NT>), dim3(xchunks*n*n), dim3(b), lds, 0, fi, fi, N+pad, n, n, n, xchunks, 0.999f); }, 10);
 	printf("rmw19 V=%d mode=%d nt=%d block=%3u pad=%zu blocks/CU<=%u: %.3f ms  %.0f GB/s (%.1f%%)  %.0f MLUPs-equivalent\n", V, MODE, (int)NT, b, pad, blocks_per_cu, ms, 152.0*N/ms/1e6, 152.0*N/ms/1e6/80, N/ms/1e3);
 	fflush(stdout);
 }
 int main(int argc, char** argv) {
 	const unsigned n = argc > 1 ? atoi(argv[1]) : 512;
 	const size_t N = (size_t)n*n*n, padmax = 1u<<20;
-	float* fi; CHECK(hipMalloc(&fi, (N+padmax)*19*sizeof(float)));
+	const bool oop = argc > 2 && atoi(argv[2]) != 0; // second argument 1: streams are written to a second buffer (two-lattice pattern)
+	float* fi; CHECK(hipMalloc(&fi, (N+padmax)*19*sizeof(float)*(oop ? 2 : 1)));
+	float* fo = oop ? fi+(N+padmax)*19 : fi;
 	CHECK(hipMemset(fi, 0, (N+padmax)*19*sizeof(float)));
 	{
 		const size_t n4 = N*19/4/2;
@@ -138,15 +198,28 @@ int main(int argc, char** argv) {
 		CHECK(hipMemset(fi, 0, (N+padmax)*19*sizeof(float)));
 	}
 	CHECK(hipMemset(fi, 0, (N+padmax)*19*sizeof(float)));
+	if (argc > 3) { // third argument: 16-bit stream sweep only
+		auto sweep16 = [&](auto kern, int V, int shift, int work) {
+			for (unsigned k : {0u, 2u, 3u, 4u, 6u}) {
+				const unsigned lanes = n/V, b = 256u > lanes ? lanes : 256u, xchunks = (lanes+b-1)/b;
+				const unsigned lds = k ? (160u*1024u/k)&~255u : 0u;
+				const float ms = time_ms([&]() { hipLaunchKernelGGL(kern, dim3(xchunks*n*n), dim3(b), lds, 0, (unsigned short*)fi, N, n, n, n, xchunks, 0.999f); }, 6);
+				printf("rmw16 V=%d shift=%d work=%d blocks/CU<=%u: %.3f ms %5.0f GB/s (%.1f%%)\n", V, shift, work, k, ms, 76.0*N/ms/1e6, 76.0*N/ms/1e6/80); fflush(stdout);
+			}
+		};
+		sweep16(k_rmw16<1, 0, 0>, 1, 0, 0); sweep16(k_rmw16<2, 0, 0>, 2, 0, 0); sweep16(k_rmw16<2, 1, 0>, 2, 1, 0); sweep16(k_rmw16<4, 0, 0>, 4, 0, 0); sweep16(k_rmw16<4, 1, 0>, 4, 1, 0);
+		sweep16(k_rmw16<2, 0, 8>, 2, 0, 8); sweep16(k_rmw16<2, 1, 8>, 2, 1, 8); sweep16(k_rmw16<2, 0, 16>, 2, 0, 16); sweep16(k_rmw16<2, 1, 16>, 2, 1, 16);
+		return 0;
+	}
 	struct R { float gbs; char name[96]; };
 	std::vector<R> res;
 	auto sweep = [&](auto kern, int V, int ntl, int nts) {
 		for (unsigned block : {128u, 256u}) for (unsigned k : {0u, 1u, 2u, 3u, 4u, 6u}) for (size_t pad : {(size_t)0, (size_t)4160}) {
 			const unsigned lanes = n/V, b = block > lanes ? lanes : block, xchunks = (lanes+b-1)/b;
 			const unsigned lds = k ? (160u*1024u/k)&~255u : 0u;
-			const float ms = time_ms([&]() { hipLaunchKernelGGL(kern, dim3(xchunks*n*n), dim3(b), lds, 0, fi, N+pad, n, n, n, xchunks, 0.999f); }, 6);
+			const float ms = time_ms([&]() { hipLaunchKernelGGL(kern, dim3(xchunks*n*n), dim3(b), lds, 0, fi, fo, N+pad, n, n, n, xchunks, 0.999f); }, 6);
 			R r; r.gbs = 152.0*N/ms/1e6;
-			snprintf(r.name, sizeof(r.name), "V=%d ntload=%d ntstore=%d block=%u blocks/CU<=%u pad=%zu", V, ntl, nts, b, k, pad);
+			snprintf(r.name, sizeof(r.name), "%sV=%d ntload=%d ntstore=%d block=%u blocks/CU<=%u pad=%zu", oop ? "two-buffer " : "", V, ntl, nts, b, k, pad);
 			res.push_back(r);
 		}
 	};
