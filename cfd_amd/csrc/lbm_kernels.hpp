@@ -188,6 +188,148 @@ __global__ __launch_bounds__(256) void k_collide(const Args a) {
 	});
 }
 
+// ---------------------------------------------------------------------------------------------- stream_collide, 16-bit DDFs, 4 cells per lane
+// Same result as k_collide<...,false>, arranged for the memory system: with 2-byte DDFs a lane owns 4 consecutive cells, so
+// every stream moves as aligned 8-byte vectors (512 contiguous bytes per wave instruction).  A slot stream that belongs
+// to the +x (-x) neighbour is the same row shifted by one cell: the lane takes its own aligned vector and the first
+// (last) element of the next (previous) lane's vector through a wave shuffle; only the lane at the end of a wave or of
+// the row fetches that one element itself.  Stores mirror this.  The 4 cells are decoded, collided and encoded one after
+// the other, the encoded result replacing the cell's element in the raw vectors (the register image of the in-place
+// update in memory), which keeps the register count near that of one cell.  A skipped cell (solid, halo) keeps the bits
+// that were read and they are written back unchanged: every slot has exactly one owner cell per step (kernel.cpp:1332-1345),
+// so nothing else touches them in between.  Waves without any active cell leave before loading anything.
+template <int Q, int ST, int COLL, int FEAT>
+__global__ __launch_bounds__(256) void k_collide_wide(const Args a) {
+	using S = Store<ST>;
+	using raw = typename S::raw;
+	static_assert(sizeof(raw) == 2, "the wide kernel is for the 16-bit DDF formats");
+	constexpr int V = 4;
+	typedef raw rvec __attribute__((ext_vector_type(4)));
+	typedef uint8_t fvec __attribute__((ext_vector_type(4)));
+	const uint32_t chunk = blockIdx.x%a.xchunks, y = blockIdx.x/a.xchunks, z = a.z0+blockIdx.y;
+	if (a.hy && (y == 0u || y == a.Ny-1u)) return;
+	const uint32_t x = (chunk*blockDim.x+threadIdx.x)*V, lane = threadIdx.x&63u;
+	const bool inrow = x < a.Nx; // lanes past the row end stay for the shuffles but touch no memory
+	const uint32_t yq[3] = {y, y+1u == a.Ny ? 0u : y+1u, y == 0u ? a.Ny-1u : y-1u}; // index 0: same, 1: +1, 2: -1 (kernel.cpp:914-925)
+	const uint32_t zq[3] = {z, z+1u == a.Nz ? 0u : z+1u, z == 0u ? a.Nz-1u : z-1u};
+	const uint64_t row0 = ((uint64_t)z*a.Ny+y)*a.Nx;
+	raw* const fi = static_cast<raw*>(a.fi);
+	auto feat = [&]() { if constexpr (FEAT >= 0) return StaticFeat<(uint32_t)(FEAT >= 0 ? FEAT : 0)>{}; else return DynamicFeat{a.features}; }();
+
+	fvec fl = {TYPE_S, TYPE_S, TYPE_S, TYPE_S};
+	if (inrow) fl = *reinterpret_cast<const fvec*>(a.flags+row0+x);
+	bool active[V];
+	bool any = false;
+#pragma unroll
+	for (int v = 0; v < V; v++) {
+		const uint32_t xv = x+(uint32_t)v;
+		active[v] = inrow && (fl[v]&TYPE_BO) != TYPE_S && !(a.hx && (xv == 0u || xv == a.Nx-1u)); // kernel.cpp:1482-1485
+		any = any || active[v];
+	}
+	if (__ballot(any) == 0ull) return;
+
+	// the lane whose +x (-x) partner lane is in another wave or past the row end fetches / stores the seam element itself
+	const bool seam_hi = lane == 63u || x+(uint32_t)V >= a.Nx, seam_lo = lane == 0u;
+	const uint32_t x_hi = x+(uint32_t)V >= a.Nx ? x+(uint32_t)V-a.Nx : x+(uint32_t)V; // cell x+4, periodic
+	const uint32_t x_lo = x == 0u ? a.Nx-1u : x-1u;                                       // cell x-1, periodic
+
+	// ---- streaming part 2 (kernel.cpp:1332-1338): d[i] = raw DDFs of direction i for the 4 cells
+	rvec d[Q];
+	raw seam[Q];
+	static_for<0, Q, 1>([&](auto I) { d[I] = rvec{0, 0, 0, 0}; seam[I] = 0; });
+	if (inrow) {
+		d[0] = *reinterpret_cast<const rvec*>(fi+row0+x);
+		static_for<1, Q, 2>([&](auto I) {
+			constexpr int i = I, cx = dir<Q>(i,0), cy = dir<Q>(i,1), cz = dir<Q>(i,2);
+			const uint32_t sA = a.odd ? i : i+1, sB = a.odd ? i+1 : i;
+			d[i] = *reinterpret_cast<const rvec*>(fi+(uint64_t)sA*a.N+row0+x);
+			const raw* pn = fi+(uint64_t)sB*a.N+((uint64_t)zq[cz == 0 ? 0 : cz > 0 ? 1 : 2]*a.Ny+yq[cy == 0 ? 0 : cy > 0 ? 1 : 2])*a.Nx;
+			d[i+1] = *reinterpret_cast<const rvec*>(pn+x); // cells x..x+3 of the neighbour row; shifted below when cx != 0
+			if constexpr (cx > 0) { if (seam_hi) seam[i+1] = pn[x_hi]; }
+			if constexpr (cx < 0) { if (seam_lo) seam[i+1] = pn[x_lo]; }
+		});
+	}
+	static_for<1, Q, 2>([&](auto I) {
+		constexpr int i = I, cx = dir<Q>(i,0);
+		if constexpr (cx > 0) { // wanted: cells x+1..x+4
+			const uint32_t next_first = __shfl_down((uint32_t)d[i+1][0], 1);
+			const raw last = seam_hi ? seam[i+1] : (raw)next_first;
+			d[i+1] = rvec{d[i+1][1], d[i+1][2], d[i+1][3], last};
+		} else if constexpr (cx < 0) { // wanted: cells x-1..x+2
+			const uint32_t prev_last = __shfl_up((uint32_t)d[i+1][3], 1);
+			const raw first = seam_lo ? seam[i+1] : (raw)prev_last;
+			d[i+1] = rvec{first, d[i+1][0], d[i+1][1], d[i+1][2]};
+		}
+	});
+
+	// ---- the 4 cells, one after the other
+#pragma unroll
+	for (int v = 0; v < V; v++) {
+		if (active[v]) {
+			const uint32_t xv = x+(uint32_t)v;
+			const uint64_t n = row0+xv;
+			const uint8_t bo = fl[v]&TYPE_BO;
+			float f[Q];
+			static_for<0, Q, 1>([&](auto I) { f[I] = S::decode(d[I][v]); });
+			if (feat(F_MOVING_BOUNDARIES) && bo == TYPE_MS) { // kernel.cpp:1111-1118
+				const uint32_t xq[3] = {xv, xv+1u == a.Nx ? 0u : xv+1u, xv == 0u ? a.Nx-1u : xv-1u};
+				static_for<1, Q, 2>([&](auto I) {
+					constexpr int i = I;
+					constexpr float w6 = -6.0f*weight<Q>(i);
+					auto nb = [&](auto J) -> uint64_t {
+						constexpr int jx = dir<Q>(J,0), jy = dir<Q>(J,1), jz = dir<Q>(J,2);
+						return ((uint64_t)zq[jz == 0 ? 0 : jz > 0 ? 1 : 2]*a.Ny+yq[jy == 0 ? 0 : jy > 0 ? 1 : 2])*a.Nx+xq[jx == 0 ? 0 : jx > 0 ? 1 : 2];
+					};
+					uint64_t ji = nb(std::integral_constant<int, i+1>{});
+					if ((a.flags[ji]&TYPE_BO) == TYPE_S) f[i] = fmaf(w6, cdot<Q, i+1>(a.u[ji], a.u[a.N+ji], a.u[2ull*a.N+ji]), f[i]);
+					ji = nb(std::integral_constant<int, i>{});
+					if ((a.flags[ji]&TYPE_BO) == TYPE_S) f[i+1] = fmaf(w6, cdot<Q, i>(a.u[ji], a.u[a.N+ji], a.u[2ull*a.N+ji]), f[i+1]);
+				});
+			}
+			float rhon, uxn, uyn, uzn;
+			bool wf = false;
+			collide<Q, COLL, false>(f, feat, bo, a, n, rhon, uxn, uyn, uzn, wf);
+			if (feat(F_UPDATE_FIELDS) && wf) { a.rho[n] = rhon; a.u[n] = uxn; a.u[a.N+n] = uyn; a.u[2ull*a.N+n] = uzn; } // kernel.cpp:1581-1591
+			// streaming part 1 in registers: the slot that held f[i] receives f[i+1] and vice versa (kernel.cpp:1339-1345)
+			d[0][v] = S::encode(f[0]);
+			static_for<1, Q, 2>([&](auto I) {
+				constexpr int i = I;
+				d[i][v] = S::encode(f[i+1]);
+				d[i+1][v] = S::encode(f[i]);
+			});
+		}
+		__builtin_amdgcn_sched_barrier(0); // keep the cells apart: interleaving them multiplies the live registers
+	}
+
+	// ---- streaming part 1 (kernel.cpp:1339-1345): write every vector back to where it came from
+	uint32_t carry[Q]; // for shifted streams: the element that belongs into the neighbouring lane's aligned vector
+	static_for<1, Q, 2>([&](auto I) {
+		constexpr int i = I, cx = dir<Q>(i,0);
+		carry[i+1] = 0u;
+		if constexpr (cx > 0) carry[i+1] = __shfl_up((uint32_t)d[i+1][3], 1);   // previous lane's value for cell x
+		if constexpr (cx < 0) carry[i+1] = __shfl_down((uint32_t)d[i+1][0], 1); // next lane's value for cell x+3
+	});
+	if (!inrow) return;
+	*reinterpret_cast<rvec*>(fi+row0+x) = d[0];
+	static_for<1, Q, 2>([&](auto I) {
+		constexpr int i = I, cx = dir<Q>(i,0), cy = dir<Q>(i,1), cz = dir<Q>(i,2);
+		const uint32_t sA = a.odd ? i : i+1, sB = a.odd ? i+1 : i;
+		*reinterpret_cast<rvec*>(fi+(uint64_t)sA*a.N+row0+x) = d[i];
+		raw* pn = fi+(uint64_t)sB*a.N+((uint64_t)zq[cz == 0 ? 0 : cz > 0 ? 1 : 2]*a.Ny+yq[cy == 0 ? 0 : cy > 0 ? 1 : 2])*a.Nx;
+		if constexpr (cx == 0) *reinterpret_cast<rvec*>(pn+x) = d[i+1];
+		else if constexpr (cx > 0) { // d[i+1] holds cells x+1..x+4
+			if (!seam_lo) *reinterpret_cast<rvec*>(pn+x) = rvec{(raw)carry[i+1], d[i+1][0], d[i+1][1], d[i+1][2]};
+			else { pn[x+1u] = d[i+1][0]; pn[x+2u] = d[i+1][1]; pn[x+3u] = d[i+1][2]; } // cell x comes from the previous wave's last lane
+			if (seam_hi) pn[x_hi] = d[i+1][3];
+		} else { // d[i+1] holds cells x-1..x+2
+			const bool seam_top = lane == 63u || x+(uint32_t)V >= a.Nx; // the next lane is in another wave or does not exist
+			if (!seam_top) *reinterpret_cast<rvec*>(pn+x) = rvec{d[i+1][1], d[i+1][2], d[i+1][3], (raw)carry[i+1]};
+			else { pn[x] = d[i+1][1]; pn[x+1u] = d[i+1][2]; pn[x+2u] = d[i+1][3]; } // cell x+3 comes from the next wave's first lane
+			if (seam_lo) pn[x_lo] = d[i+1][0];
+		}
+	});
+}
+
 #ifdef LBM_SMALL_KERNELS // the one-cell-per-thread kernels are compiled once, in lbmhip.hip
 // ---------------------------------------------------------------------------------------------- one-cell-per-thread helpers
 struct Cell { uint32_t x, y, z; uint64_t n; bool valid; };

@@ -329,19 +329,26 @@ static int launch_collide_planes(lbmhip_domain* d, uint64_t t, float fx, float f
 	if (z1 > d->cfg.Nz-hz) z1 = d->cfg.Nz-hz;
 	if (z0 >= z1) return 0;
 	// Launch geometry.  Measured on MI355X at 512^3: FP32 is fastest with one cell per lane (dword accesses), 256-lane
-	// workgroups and at most 12 waves resident per CU (more waves in flight lower the achieved HBM bandwidth by ~15 %);
-	// FP16S wants 2 cells per lane (dword accesses again), FP16C (conversion-heavy) 1; neither gains from a residency cap.
+	// workgroups and at most 12 waves resident per CU (more waves in flight lower the achieved HBM bandwidth by ~15 %).
+	// The 16-bit formats are fastest with the 4-cells-per-lane kernel (aligned 8-byte accesses, shifted streams rebuilt
+	// with wave shuffles); rows that are not a multiple of 4 cells fall back to 2 (FP16S) or 1 (FP16C) cells per lane.
 	const bool small = d->cfg.velocity_set == 9u || d->cfg.velocity_set == 15u;
+	const bool half = d->cfg.storage != LBMHIP_FP32;
 	int V = fields_only ? 1 : d->cells_per_thread;
-	if (V == 0) V = d->cfg.storage == LBMHIP_FP16S ? 2 : 1;
+	if (V == 0) V = half ? 4 : d->cfg.velocity_set == 27u ? 2 : 1; // D3Q27 FP32: 27 dword streams per lane leave too little in flight
 	if (small) V = 1;
 	while (V > 1 && d->cfg.Nx%(uint32_t)V != 0u) V /= 2; // vector accesses need rows that are whole vectors
+	if (V == 2 && d->cells_per_thread == 0 && d->cfg.storage == LBMHIP_FP16C) V = 1;
 	const uint32_t lanes_per_row = (d->cfg.Nx+(uint32_t)V-1u)/(uint32_t)V;
 	uint32_t block = d->block ? (uint32_t)d->block : 256u;
 	const uint32_t need = (lanes_per_row+63u)/64u*64u;
 	if (block > need) block = need;
 	int blocks_per_cu = d->blocks_per_cu;
-	if (blocks_per_cu < 0) blocks_per_cu = (d->cfg.storage == LBMHIP_FP32 && !fields_only) ? (int)std::max(1u, 12u/(block/64u)) : 0;
+	if (blocks_per_cu < 0) {
+		if (fields_only) blocks_per_cu = 0;
+		else if (!half) blocks_per_cu = d->cfg.velocity_set == 19u ? (int)std::max(1u, 12u/(block/64u)) : 0;
+		else blocks_per_cu = (d->cfg.storage == LBMHIP_FP16S && d->cfg.velocity_set == 19u && V == 4) ? 7 : 0;
+	}
 	Args a = make_args(d, t, fx, fy, fz);
 	a.z0 = z0; a.z1 = z1;
 	a.xchunks = (lanes_per_row+block-1u)/block;

@@ -58,7 +58,7 @@ def test_parity_against_oracle(gpu, name):
 
 
 @pytest.mark.parametrize("cells_per_thread", [1, 2, 4])
-@pytest.mark.parametrize("name", ["tgv32_fp32_srt", "cavity32_fp32_srt", "gui_fp16s_srt", "q27_fp16c_force", "all_fp32_srt_8dom"])
+@pytest.mark.parametrize("name", ["tgv32_fp32_srt", "cavity32_fp32_srt", "gui_fp16s_srt", "q27_fp16c_force", "all_fp32_srt_8dom", "all_fp16s_trt_2dom", "q19_fp16c_srt"])
 def test_vector_widths_agree(gpu, name, cells_per_thread):
     case = CASES[name]
     a, b = run_pair(case, tuning={"cells_per_thread": cells_per_thread})
