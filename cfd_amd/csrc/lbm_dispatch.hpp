@@ -13,17 +13,17 @@ hipError_t launch_collide(const Args& a, dim3 grid, dim3 block, uint32_t lds_byt
 	return hipGetLastError();
 }
 
-template <int Q, int ST, int COLL, int FEAT>
+template <int Q, int ST, int COLL, int FEAT, int V>
 hipError_t launch_collide_wide(const Args& a, dim3 grid, dim3 block, uint32_t lds_bytes, hipStream_t stream) {
-	hipLaunchKernelGGL((k_collide_wide<Q, ST, COLL, FEAT>), grid, block, lds_bytes, stream, a);
+	hipLaunchKernelGGL((k_collide_wide<Q, ST, COLL, FEAT, V>), grid, block, lds_bytes, stream, a);
 	return hipGetLastError();
 }
 
 // FEAT < 0 selects the instance that reads the feature mask at run time; FO = update_fields (always run-time features, V=1)
 template <int Q, int ST, int COLL, int FEAT> collide_launch_fn pick_v(int V) {
 	switch (V) {
-		case 4: if constexpr (ST == ST_FP32) return launch_collide<Q, ST, COLL, FEAT, 4, false>; else return launch_collide_wide<Q, ST, COLL, FEAT>;
-		case 2: return launch_collide<Q, ST, COLL, FEAT, 2, false>;
+		case 4: return launch_collide_wide<Q, ST, COLL, FEAT, 4>;
+		case 2: if constexpr (ST == ST_FP32) return launch_collide_wide<Q, ST, COLL, FEAT, 2>; else return launch_collide<Q, ST, COLL, FEAT, 2, false>;
 		default: return launch_collide<Q, ST, COLL, FEAT, 1, false>;
 	}
 }

@@ -188,24 +188,24 @@ __global__ __launch_bounds__(256) void k_collide(const Args a) {
 	});
 }
 
-// ---------------------------------------------------------------------------------------------- stream_collide, 16-bit DDFs, 4 cells per lane
-// Same result as k_collide<...,false>, arranged for the memory system: with 2-byte DDFs a lane owns 4 consecutive cells, so
-// every stream moves as aligned 8-byte vectors (512 contiguous bytes per wave instruction).  A slot stream that belongs
+// ---------------------------------------------------------------------------------------------- stream_collide, V cells per lane, aligned vectors only
+// Same result as k_collide<...,false>, arranged for the memory system: a lane owns V consecutive cells and every stream
+// moves as aligned V*sizeof(raw)-byte vectors (4 cells of 16-bit DDFs: 512 contiguous bytes per wave instruction).  A slot stream that belongs
 // to the +x (-x) neighbour is the same row shifted by one cell: the lane takes its own aligned vector and the first
 // (last) element of the next (previous) lane's vector through a wave shuffle; only the lane at the end of a wave or of
-// the row fetches that one element itself.  Stores mirror this.  The 4 cells are decoded, collided and encoded one after
+// the row fetches that one element itself.  Stores mirror this.  The V cells are decoded, collided and encoded one after
 // the other, the encoded result replacing the cell's element in the raw vectors (the register image of the in-place
 // update in memory), which keeps the register count near that of one cell.  A skipped cell (solid, halo) keeps the bits
 // that were read and they are written back unchanged: every slot has exactly one owner cell per step (kernel.cpp:1332-1345),
 // so nothing else touches them in between.  Waves without any active cell leave before loading anything.
-template <int Q, int ST, int COLL, int FEAT>
+template <int Q, int ST, int COLL, int FEAT, int V>
 __global__ __launch_bounds__(256) void k_collide_wide(const Args a) {
 	using S = Store<ST>;
 	using raw = typename S::raw;
-	static_assert(sizeof(raw) == 2, "the wide kernel is for the 16-bit DDF formats");
-	constexpr int V = 4;
-	typedef raw rvec __attribute__((ext_vector_type(4)));
-	typedef uint8_t fvec __attribute__((ext_vector_type(4)));
+	static_assert(V == 2 || V == 4, "vectors of 2 or 4 cells");
+	typedef raw rvec __attribute__((ext_vector_type(V)));
+	typedef uint8_t fvec __attribute__((ext_vector_type(V)));
+	typedef typename std::conditional<sizeof(raw) == 2, uint32_t, raw>::type lane_t; // what travels through a wave shuffle
 	const uint32_t chunk = blockIdx.x%a.xchunks, y = blockIdx.x/a.xchunks, z = a.z0+blockIdx.y;
 	if (a.hy && (y == 0u || y == a.Ny-1u)) return;
 	const uint32_t x = (chunk*blockDim.x+threadIdx.x)*V, lane = threadIdx.x&63u;
@@ -216,7 +216,9 @@ __global__ __launch_bounds__(256) void k_collide_wide(const Args a) {
 	raw* const fi = static_cast<raw*>(a.fi);
 	auto feat = [&]() { if constexpr (FEAT >= 0) return StaticFeat<(uint32_t)(FEAT >= 0 ? FEAT : 0)>{}; else return DynamicFeat{a.features}; }();
 
-	fvec fl = {TYPE_S, TYPE_S, TYPE_S, TYPE_S};
+	fvec fl;
+#pragma unroll
+	for (int v = 0; v < V; v++) fl[v] = TYPE_S;
 	if (inrow) fl = *reinterpret_cast<const fvec*>(a.flags+row0+x);
 	bool active[V];
 	bool any = false;
@@ -230,13 +232,13 @@ __global__ __launch_bounds__(256) void k_collide_wide(const Args a) {
 
 	// the lane whose +x (-x) partner lane is in another wave or past the row end fetches / stores the seam element itself
 	const bool seam_hi = lane == 63u || x+(uint32_t)V >= a.Nx, seam_lo = lane == 0u;
-	const uint32_t x_hi = x+(uint32_t)V >= a.Nx ? x+(uint32_t)V-a.Nx : x+(uint32_t)V; // cell x+4, periodic
+	const uint32_t x_hi = x+(uint32_t)V >= a.Nx ? x+(uint32_t)V-a.Nx : x+(uint32_t)V; // cell x+V, periodic
 	const uint32_t x_lo = x == 0u ? a.Nx-1u : x-1u;                                       // cell x-1, periodic
 
 	// ---- streaming part 2 (kernel.cpp:1332-1338): d[i] = raw DDFs of direction i for the 4 cells
 	rvec d[Q];
 	raw seam[Q];
-	static_for<0, Q, 1>([&](auto I) { d[I] = rvec{0, 0, 0, 0}; seam[I] = 0; });
+	static_for<0, Q, 1>([&](auto I) { d[I] = rvec(0); seam[I] = 0; });
 	if (inrow) {
 		d[0] = *reinterpret_cast<const rvec*>(fi+row0+x);
 		static_for<1, Q, 2>([&](auto I) {
@@ -251,18 +253,26 @@ __global__ __launch_bounds__(256) void k_collide_wide(const Args a) {
 	}
 	static_for<1, Q, 2>([&](auto I) {
 		constexpr int i = I, cx = dir<Q>(i,0);
-		if constexpr (cx > 0) { // wanted: cells x+1..x+4
-			const uint32_t next_first = __shfl_down((uint32_t)d[i+1][0], 1);
+		if constexpr (cx > 0) { // wanted: cells x+1..x+V
+			const lane_t next_first = __shfl_down((lane_t)d[i+1][0], 1);
 			const raw last = seam_hi ? seam[i+1] : (raw)next_first;
-			d[i+1] = rvec{d[i+1][1], d[i+1][2], d[i+1][3], last};
-		} else if constexpr (cx < 0) { // wanted: cells x-1..x+2
-			const uint32_t prev_last = __shfl_up((uint32_t)d[i+1][3], 1);
+			rvec t;
+#pragma unroll
+			for (int v = 0; v+1 < V; v++) t[v] = d[i+1][v+1];
+			t[V-1] = last;
+			d[i+1] = t;
+		} else if constexpr (cx < 0) { // wanted: cells x-1..x+V-2
+			const lane_t prev_last = __shfl_up((lane_t)d[i+1][V-1], 1);
 			const raw first = seam_lo ? seam[i+1] : (raw)prev_last;
-			d[i+1] = rvec{first, d[i+1][0], d[i+1][1], d[i+1][2]};
+			rvec t;
+			t[0] = first;
+#pragma unroll
+			for (int v = 1; v < V; v++) t[v] = d[i+1][v-1];
+			d[i+1] = t;
 		}
 	});
 
-	// ---- the 4 cells, one after the other
+	// ---- the V cells, one after the other
 #pragma unroll
 	for (int v = 0; v < V; v++) {
 		if (active[v]) {
@@ -302,12 +312,12 @@ __global__ __launch_bounds__(256) void k_collide_wide(const Args a) {
 	}
 
 	// ---- streaming part 1 (kernel.cpp:1339-1345): write every vector back to where it came from
-	uint32_t carry[Q]; // for shifted streams: the element that belongs into the neighbouring lane's aligned vector
+	lane_t carry[Q]; // for shifted streams: the element that belongs into the neighbouring lane's aligned vector
 	static_for<1, Q, 2>([&](auto I) {
 		constexpr int i = I, cx = dir<Q>(i,0);
-		carry[i+1] = 0u;
-		if constexpr (cx > 0) carry[i+1] = __shfl_up((uint32_t)d[i+1][3], 1);   // previous lane's value for cell x
-		if constexpr (cx < 0) carry[i+1] = __shfl_down((uint32_t)d[i+1][0], 1); // next lane's value for cell x+3
+		carry[i+1] = 0;
+		if constexpr (cx > 0) carry[i+1] = __shfl_up((lane_t)d[i+1][V-1], 1); // previous lane's value for cell x
+		if constexpr (cx < 0) carry[i+1] = __shfl_down((lane_t)d[i+1][0], 1); // next lane's value for cell x+V-1
 	});
 	if (!inrow) return;
 	*reinterpret_cast<rvec*>(fi+row0+x) = d[0];
@@ -317,14 +327,29 @@ __global__ __launch_bounds__(256) void k_collide_wide(const Args a) {
 		*reinterpret_cast<rvec*>(fi+(uint64_t)sA*a.N+row0+x) = d[i];
 		raw* pn = fi+(uint64_t)sB*a.N+((uint64_t)zq[cz == 0 ? 0 : cz > 0 ? 1 : 2]*a.Ny+yq[cy == 0 ? 0 : cy > 0 ? 1 : 2])*a.Nx;
 		if constexpr (cx == 0) *reinterpret_cast<rvec*>(pn+x) = d[i+1];
-		else if constexpr (cx > 0) { // d[i+1] holds cells x+1..x+4
-			if (!seam_lo) *reinterpret_cast<rvec*>(pn+x) = rvec{(raw)carry[i+1], d[i+1][0], d[i+1][1], d[i+1][2]};
-			else { pn[x+1u] = d[i+1][0]; pn[x+2u] = d[i+1][1]; pn[x+3u] = d[i+1][2]; } // cell x comes from the previous wave's last lane
-			if (seam_hi) pn[x_hi] = d[i+1][3];
-		} else { // d[i+1] holds cells x-1..x+2
-			const bool seam_top = lane == 63u || x+(uint32_t)V >= a.Nx; // the next lane is in another wave or does not exist
-			if (!seam_top) *reinterpret_cast<rvec*>(pn+x) = rvec{d[i+1][1], d[i+1][2], d[i+1][3], (raw)carry[i+1]};
-			else { pn[x] = d[i+1][1]; pn[x+1u] = d[i+1][2]; pn[x+2u] = d[i+1][3]; } // cell x+3 comes from the next wave's first lane
+		else if constexpr (cx > 0) { // d[i+1] holds cells x+1..x+V
+			if (!seam_lo) {
+				rvec t;
+				t[0] = (raw)carry[i+1];
+#pragma unroll
+				for (int v = 1; v < V; v++) t[v] = d[i+1][v-1];
+				*reinterpret_cast<rvec*>(pn+x) = t;
+			} else { // cell x comes from the previous wave's last lane
+#pragma unroll
+				for (int v = 1; v < V; v++) pn[x+(uint32_t)v] = d[i+1][v-1];
+			}
+			if (seam_hi) pn[x_hi] = d[i+1][V-1];
+		} else { // d[i+1] holds cells x-1..x+V-2
+			if (!seam_hi) {
+				rvec t;
+#pragma unroll
+				for (int v = 0; v+1 < V; v++) t[v] = d[i+1][v+1];
+				t[V-1] = (raw)carry[i+1];
+				*reinterpret_cast<rvec*>(pn+x) = t;
+			} else { // cell x+V-1 comes from the next wave's first lane
+#pragma unroll
+				for (int v = 0; v+1 < V; v++) pn[x+(uint32_t)v] = d[i+1][v+1];
+			}
 			if (seam_lo) pn[x_lo] = d[i+1][0];
 		}
 	});

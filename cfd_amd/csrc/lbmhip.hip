@@ -346,7 +346,7 @@ static int launch_collide_planes(lbmhip_domain* d, uint64_t t, float fx, float f
 	int blocks_per_cu = d->blocks_per_cu;
 	if (blocks_per_cu < 0) {
 		if (fields_only) blocks_per_cu = 0;
-		else if (!half) blocks_per_cu = d->cfg.velocity_set == 19u ? (int)std::max(1u, 12u/(block/64u)) : 0;
+		else if (!half) blocks_per_cu = (int)std::max(1u, (d->cfg.velocity_set == 27u ? 16u : 12u)/(block/64u));
 		else blocks_per_cu = (d->cfg.storage == LBMHIP_FP16S && d->cfg.velocity_set == 19u && V == 4) ? 7 : 0;
 	}
 	Args a = make_args(d, t, fx, fy, fz);

@@ -35,7 +35,7 @@ with open(os.path.join(dst, "%s_pmc_summary.csv" % tag), "w") as f:
     for r in sorted(rows):
         w.writerow(r)
 
-main = [k for k in counters if "k_collide" in k]
+main = sorted((k for k in counters if "k_collide" in k), key=lambda k: -len(counters[k].get("FETCH_SIZE", [])))  # the step kernel has the most dispatches
 out = {"tag": tag, "bench": bench}
 if main:
     c = counters[main[0]]
