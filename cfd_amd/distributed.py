@@ -18,6 +18,7 @@ never touch the same memory.
 The slab engine is abstract (SlabOps) so that the exchange logic can be driven by CPU tensors in tests; the
 product implementation is HipSlabOps (HIP kernels through the C ABI, staging buffers owned by torch).
 """
+import contextlib
 import ctypes as C
 
 import numpy as np
@@ -43,6 +44,7 @@ class SlabOps:
     def pack(self, what, t): raise NotImplementedError
     def unpack(self, what, t): raise NotImplementedError
     def halo_bytes(self, what): raise NotImplementedError
+    def scope(self): return contextlib.nullcontext()  # makes the engine's compute stream the current one for the block
     def fork(self): pass       # communication stream waits for the compute stream and becomes current
     def end_fork(self): pass   # back to the compute stream
     def join(self): pass       # compute stream waits for the communication stream
@@ -116,6 +118,11 @@ class HipSlabOps(SlabOps):
         n = C.c_uint64()
         L.check(self.lib.lbmhip_halo_bytes(self.dom.h, WHAT[what], 2, C.byref(n)))
         return n.value
+
+    def scope(self):
+        # torch.distributed orders its transfers against torch's CURRENT stream, so the stream the kernels are launched
+        # on has to be the current one whenever an exchange is issued
+        return torch.cuda.stream(self.compute)
 
     def fork(self):
         self.comm.wait_stream(self.compute)
@@ -215,6 +222,10 @@ class DistributedLBM:
 
     # ---- LBM::initialize (lbm.cpp:1354-1409)
     def initialize(self):
+        with self.ops.scope():
+            self._initialize()
+
+    def _initialize(self):
         Lx, Ly, Lz = self.local
         hz = self.hz
         rho = np.ones((Lz, Ly, Lx), dtype=np.float32); rho[hz:Lz - hz] = self.rho
@@ -238,6 +249,10 @@ class DistributedLBM:
 
     # ---- LBM::do_time_step (lbm.cpp:1411-1459)
     def do_time_step(self):
+        with self.ops.scope():
+            self._do_time_step()
+
+    def _do_time_step(self):
         Lz = self.local[2]
         o = self.ops
         if self.world <= 1:
@@ -260,10 +275,11 @@ class DistributedLBM:
             self.t_last_update_fields = self.t
 
     def run(self, steps):
-        if not self.initialized:
-            self.initialize()
-        for _ in range(int(steps)):
-            self.do_time_step()
+        with self.ops.scope():
+            if not self.initialized:
+                self._initialize()
+            for _ in range(int(steps)):
+                self._do_time_step()
         self.ops.sync()
 
     def update_fields(self):
