@@ -113,3 +113,37 @@ def test_object_sums_match_host_definition(gpu):
             assert np.allclose(force, want_force, rtol=1e-4, atol=1e-7)
             assert np.allclose(torque, want_torque, rtol=1e-4, atol=1e-6)
             assert np.allclose(com, want_com, rtol=1e-5, atol=1e-4)
+
+
+RAGGED = {
+    # rows that are not a multiple of the vector width, rows shorter than a wave, x/y halos under the wide kernel
+    "fp16s_30x14x10": dict(kw=dict(N=(30, 14, 10), nu=0.02, storage="FP16S"), setup="tgv"),
+    "fp16c_31x9x7": dict(kw=dict(N=(31, 9, 7), nu=0.02, storage="FP16C", collision="TRT"), setup="tgv"),
+    "fp16s_36x10x6_wide": dict(kw=dict(N=(36, 10, 6), nu=0.02, storage="FP16S", features=("VOLUME_FORCE", "SUBGRID"), f=(1e-4, 0.0, 0.0)), setup="channel"),
+    "fp16s_xy_halo_all": dict(kw=dict(N=(72, 24, 8), nu=0.01, D=(2, 2, 1), storage="FP16S", collision="TRT",
+                                      features=("UPDATE_FIELDS", "VOLUME_FORCE", "MOVING_BOUNDARIES", "EQUILIBRIUM_BOUNDARIES", "FORCE_FIELD", "SUBGRID"), f=(1e-4, 0.0, 0.0)), setup="all"),
+    "fp16c_q27_x_halo": dict(kw=dict(N=(80, 12, 12), nu=0.02, D=(2, 1, 1), Q=27, storage="FP16C", features=("EQUILIBRIUM_BOUNDARIES",)), setup="inflow"),
+    "fp32_q27_x_halo_v2": dict(kw=dict(N=(44, 12, 12), nu=0.02, D=(2, 1, 1), Q=27, features=("MOVING_BOUNDARIES",)), setup="cavity"),
+    "fp32_260x6x6": dict(kw=dict(N=(260, 6, 6), nu=0.02), setup="tgv"),
+    "fp16s_1028x4x4_wide": dict(kw=dict(N=(1028, 4, 4), nu=0.02, storage="FP16S"), setup="tgv"),
+    "q15_fp16s_3dom": dict(kw=dict(N=(24, 24, 12), nu=0.02, Q=15, D=(1, 3, 1), storage="FP16S"), setup="tgv"),
+    "q9_fp16c_4dom": dict(kw=dict(N=(40, 24, 1), nu=0.02, Q=9, D=(2, 2, 1), storage="FP16C"), setup="tgv2d"),
+}
+
+
+@pytest.mark.parametrize("name", sorted(RAGGED))
+def test_ragged_shapes_and_halos(gpu, name):
+    from tests import cases as CS
+    from cfd_amd import setups
+    case = RAGGED[name]
+    setup = {"tgv": setups.taylor_green, "channel": CS._channel_setup, "all": CS._all_features_setup, "inflow": setups.inflow_box,
+             "cavity": setups.lid_cavity, "tgv2d": CS._tgv2d}[case["setup"]]
+    a, b = run_pair(dict(kw=case["kw"], setup=setup))
+    try:
+        a.run(1); b.run(1)
+        compare(a, b, name + " t=1")
+        a.run(11); b.run(11)
+        compare(a, b, name + " t=12")
+        assert np.isfinite(a.u).all()
+    finally:
+        a.close()
