@@ -114,3 +114,12 @@ def test_stokes_drag_example_object_sums(gpu):
     assert abs(force[1]) < 1e-5 * stokes and abs(force[2]) < 1e-5 * stokes
     assert max(abs(t) for t in torque) < 1e-4 * stokes * 16
     assert max(abs(c) for c in com) < 1e-3
+
+
+@pytest.mark.parametrize("name,floor", [("benchmark_fp32", 25000), ("benchmark_fp16s", 45000)])
+def test_benchmark_example_reports_peak_mlups(gpu, name, floor):
+    """The reference's benchmark setup through the C++ host (512^3 at rest, batches of 10 steps).  The floors are far below
+    what the kernels reach (35 000 / 68 000 MLUPs/s); they only catch a host that serialises the launches."""
+    out = run_example(name, env={"LBM_BENCH_BATCHES": "100"})
+    mlups = int([l for l in out.splitlines() if l.startswith("peak_mlups ")][0].split()[1])
+    assert mlups > floor, out
