@@ -61,6 +61,46 @@ def test_two_ranks_on_one_gpu_match_the_oracle(gpu, tmp_path, overlap):
         assert np.array_equal(got["u"].view(np.uint32), ref.u[:, sl].view(np.uint32))
 
 
+def _self_exchange_worker(rank, port, kw, steps, overlap, out_dir):
+    """One rank, backend nccl (= RCCL): the rank is its own z-neighbour on both sides, so its slab with halo planes is a
+    periodic lattice of nz planes.  Runs the production exchange code (device buffers, RCCL send/recv, streams)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from cfd_amd import setups
+        from cfd_amd.distributed import DistributedLBM
+        import cfd_amd
+        kw = dict(kw)
+        N = kw.pop("N")
+        lbm = DistributedLBM((N[0], N[1], 2 * N[2]), rank=0, world=2, overlap=overlap, **kw)  # 2 slabs of N[2] planes; this rank is slab 0
+        lbm.next = lbm.prev = 0
+        with cfd_amd.LBM(N, **kw) as single:
+            setups.channel(single)
+            lbm.rho[...] = single.rho; lbm.u[...] = single.u; lbm.flags[...] = single.flags
+            single.run(steps)
+            single.read_from_device()
+            lbm.run(steps)
+            lbm.read_from_device()
+            np.savez(os.path.join(out_dir, "self.npz"), rho=lbm.rho, u=lbm.u, flags=lbm.flags, rho0=single.rho, u0=single.u, flags0=single.flags)
+        lbm.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_rccl_exchange_with_itself_equals_periodic_lattice(gpu, tmp_path, overlap):
+    kw = dict(N=(64, 32, 24), nu=0.01, Q=19, storage="FP16S", collision="TRT", features=("VOLUME_FORCE", "SUBGRID"), f=(1e-4, 0.0, 0.0))
+    mp.spawn(_self_exchange_worker, args=(_free_port(), kw, 20, overlap, str(tmp_path)), nprocs=1, join=True)
+    got = np.load(os.path.join(str(tmp_path), "self.npz"))
+    assert np.array_equal(got["flags"], got["flags0"])
+    assert np.array_equal(got["rho"].view(np.uint32), got["rho0"].view(np.uint32))
+    assert np.array_equal(got["u"].view(np.uint32), got["u0"].view(np.uint32))
+    assert float(np.abs(got["u"]).max()) > 1e-4
+
+
 def test_capacity_lattice_1600_fp16s(gpu):
     """D3Q19 FP16S at 1600^3 (4.1e9 cells, 225 GB: the capacity configuration of the benchmark list).  Only a small
     block of cells is disturbed, so for a few steps its neighbourhood must evolve exactly like the same block in a small
