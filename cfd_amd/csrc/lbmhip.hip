@@ -37,6 +37,7 @@ struct lbmhip_domain {
 	uint64_t halo_capacity;
 	hipEvent_t ev_start, ev_stop, ev_packed, ev_copied;
 	int cells_per_thread, block, blocks_per_cu;
+	void* partial; // per-workgroup partial sums of the object_* reductions (kObjectSumBlocks float4)
 	float w;
 };
 
@@ -57,6 +58,7 @@ static hipError_t fill_words(void* p, uint32_t word, uint64_t count, hipStream_t
 	return hipGetLastError();
 }
 
+static const uint32_t kObjectSumBlocks = 2048u;
 static uint32_t q_transfers(uint32_t Q) { return Q == 9u ? 3u : Q == 27u ? 9u : 5u; }
 static uint32_t storage_bytes(uint32_t st) { return st == LBMHIP_FP32 ? 4u : 2u; }
 static bool valid_q(uint32_t Q) { return Q == 9u || Q == 15u || Q == 19u || Q == 27u; }
@@ -192,7 +194,8 @@ int lbmhip_domain_create(const lbmhip_config* c, lbmhip_domain** out) {
 			d->halo[k] = d->halo_own[k];
 		}
 	}
-	e = hipEventCreate(&d->ev_start);
+	e = hipMalloc(&d->partial, kObjectSumBlocks*4u*sizeof(float));
+	if (e == hipSuccess) e = hipEventCreate(&d->ev_start);
 	if (e == hipSuccess) e = hipEventCreate(&d->ev_stop);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_packed, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_copied, hipEventDisableTiming);
@@ -211,6 +214,7 @@ int lbmhip_domain_destroy(lbmhip_domain* d) {
 	if (d->own_stream) (void)hipStreamSynchronize(d->own_stream);
 	for (int k = 0; k < 5; k++) if (d->field[k]) (void)hipFree(d->field[k]);
 	for (int k = 0; k < 4; k++) if (d->halo_own[k]) (void)hipFree(d->halo_own[k]);
+	if (d->partial) (void)hipFree(d->partial);
 	if (d->ev_start) (void)hipEventDestroy(d->ev_start);
 	if (d->ev_stop) (void)hipEventDestroy(d->ev_stop);
 	if (d->ev_packed) (void)hipEventDestroy(d->ev_packed);
@@ -595,9 +599,8 @@ int lbmhip_object_sum(lbmhip_domain* d, int what, uint8_t flag_marker, const flo
 	NEED(what >= 0 && what <= 2, "what must be 0 (centre of mass), 1 (force) or 2 (torque)");
 	NEED(what == 0 || d->field[LBMHIP_FIELD_F], "force and torque sums need the FORCE_FIELD extension");
 	DeviceGuard g(d->cfg.device);
-	const uint32_t blocks = 2048u;
-	float4* partial = nullptr;
-	HIP_TRY(hipMalloc(&partial, blocks*sizeof(float4)));
+	const uint32_t blocks = kObjectSumBlocks;
+	float4* partial = static_cast<float4*>(d->partial);
 	SumArgs s;
 	s.lat = make_args(d, 0u, 0.0f, 0.0f, 0.0f);
 	s.partial = partial; s.what = (uint32_t)what; s.marker = flag_marker;
@@ -614,7 +617,6 @@ int lbmhip_object_sum(lbmhip_domain* d, int what, uint8_t flag_marker, const flo
 	std::vector<float4> host(blocks);
 	if (e == hipSuccess) e = hipMemcpyAsync(host.data(), partial, blocks*sizeof(float4), hipMemcpyDeviceToHost, d->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
-	(void)hipFree(partial);
 	if (e != hipSuccess) return fail("object sum failed: %s", hipGetErrorString(e));
 	sums[0] = sums[1] = sums[2] = sums[3] = 0.0;
 	for (uint32_t b = 0u; b < blocks; b++) { sums[0] += host[b].x; sums[1] += host[b].y; sums[2] += host[b].z; sums[3] += host[b].w; }
