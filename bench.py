@@ -56,6 +56,9 @@ def measured_traffic(workload):
         return None
 
 
+TUNE_STEPS = 52
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -98,6 +101,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    lbm.run(TUNE_STEPS)   # untimed: the library tries its launch geometries on the first full-lattice launches and keeps the fastest
     lbm.run(a.warmup)
     barrier()
     lib = cfd_amd.lib()

@@ -37,6 +37,10 @@ struct lbmhip_domain {
 	uint64_t halo_capacity;
 	hipEvent_t ev_start, ev_stop, ev_packed, ev_copied;
 	int cells_per_thread, block, blocks_per_cu;
+	// launch-geometry search over the first full-lattice stream_collide launches (results do not depend on the geometry)
+	struct { int V, blocks_per_cu; float ms; } cand[24];
+	int ncand, tune_launches, tune_pending, autotune, tuned, tuned_V, tuned_blocks_per_cu;
+	hipEvent_t ev_tune0, ev_tune1;
 	void* partial; // per-workgroup partial sums of the object_* reductions (kObjectSumBlocks float4)
 	float w;
 };
@@ -154,6 +158,8 @@ int lbmhip_domain_create(const lbmhip_config* c, lbmhip_domain** out) {
 	d->cells_per_thread = 0; // 0 = automatic
 	d->block = 0;
 	d->blocks_per_cu = -1; // -1 = automatic
+	d->tune_pending = -1;
+	{ const char* env = getenv("LBMHIP_AUTOTUNE"); d->autotune = !(env && env[0] == '0'); }
 	d->field_bytes[LBMHIP_FIELD_FI] = d->N*c->velocity_set*d->fpxx_bytes;
 	d->field_bytes[LBMHIP_FIELD_RHO] = d->N*4u;
 	d->field_bytes[LBMHIP_FIELD_U] = d->N*12u;
@@ -197,6 +203,8 @@ int lbmhip_domain_create(const lbmhip_config* c, lbmhip_domain** out) {
 	e = hipMalloc(&d->partial, kObjectSumBlocks*4u*sizeof(float));
 	if (e == hipSuccess) e = hipEventCreate(&d->ev_start);
 	if (e == hipSuccess) e = hipEventCreate(&d->ev_stop);
+	if (e == hipSuccess) e = hipEventCreate(&d->ev_tune0);
+	if (e == hipSuccess) e = hipEventCreate(&d->ev_tune1);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_packed, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_copied, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming);
@@ -217,6 +225,8 @@ int lbmhip_domain_destroy(lbmhip_domain* d) {
 	if (d->partial) (void)hipFree(d->partial);
 	if (d->ev_start) (void)hipEventDestroy(d->ev_start);
 	if (d->ev_stop) (void)hipEventDestroy(d->ev_stop);
+	if (d->ev_tune0) (void)hipEventDestroy(d->ev_tune0);
+	if (d->ev_tune1) (void)hipEventDestroy(d->ev_tune1);
 	if (d->ev_packed) (void)hipEventDestroy(d->ev_packed);
 	if (d->ev_copied) (void)hipEventDestroy(d->ev_copied);
 	if (d->ev_fork) (void)hipEventDestroy(d->ev_fork);
@@ -309,6 +319,16 @@ int lbmhip_set_tuning(lbmhip_domain* d, const char* key, int value) {
 	if (!strcmp(key, "cells_per_thread")) { NEED(value == 0 || value == 1 || value == 2 || value == 4, "cells_per_thread must be 0 (auto), 1, 2 or 4"); d->cells_per_thread = value; return 0; }
 	if (!strcmp(key, "blocks_per_cu")) { NEED(value >= -1 && value <= 32, "blocks_per_cu must be -1 (auto), 0 (no limit) or 1..32"); d->blocks_per_cu = value; return 0; }
 	if (!strcmp(key, "block")) { NEED(value == 0 || (value >= 64 && value <= 256 && value%64 == 0), "block must be 0 (auto), 64, 128, 192 or 256"); d->block = value; return 0; }
+	if (!strcmp(key, "autotune")) { NEED(value == 0 || value == 1, "autotune must be 0 or 1"); d->autotune = value; if (!value) { d->tuned = 0; d->tune_launches = 0; d->tune_pending = -1; } return 0; }
+	return fail("unknown tuning key '%s'", key);
+}
+int lbmhip_get_tuning(lbmhip_domain* d, const char* key, int* value) {
+	NEED(d && key && value, "null argument");
+	if (!strcmp(key, "cells_per_thread")) { *value = d->tuned ? d->tuned_V : d->cells_per_thread; return 0; }
+	if (!strcmp(key, "blocks_per_cu")) { *value = d->tuned ? d->tuned_blocks_per_cu : d->blocks_per_cu; return 0; }
+	if (!strcmp(key, "block")) { *value = d->block; return 0; }
+	if (!strcmp(key, "autotune")) { *value = d->autotune; return 0; }
+	if (!strcmp(key, "tuned")) { *value = d->tuned; return 0; }
 	return fail("unknown tuning key '%s'", key);
 }
 
@@ -327,15 +347,12 @@ static collide_launch_fn find_collide(const lbmhip_domain* d, int V, bool fields
 	return fn;
 }
 
-static int launch_collide_planes(lbmhip_domain* d, uint64_t t, float fx, float fy, float fz, uint32_t z0, uint32_t z1, bool fields_only) {
-	const uint32_t hz = d->cfg.Dz > 1u;
-	if (z0 < hz) z0 = hz;
-	if (z1 > d->cfg.Nz-hz) z1 = d->cfg.Nz-hz;
-	if (z0 >= z1) return 0;
-	// Launch geometry.  Measured on MI355X at 512^3: FP32 is fastest with one cell per lane (dword accesses), 256-lane
-	// workgroups and at most 12 waves resident per CU (more waves in flight lower the achieved HBM bandwidth by ~15 %).
-	// The 16-bit formats are fastest with the 4-cells-per-lane kernel (aligned 8-byte accesses, shifted streams rebuilt
-	// with wave shuffles); rows that are not a multiple of 4 cells fall back to 2 (FP16S) or 1 (FP16C) cells per lane.
+// Default launch geometry.  Measured on MI355X at 512^3: plain FP32 D3Q19 is fastest with one cell per lane (dword
+// accesses), 256-lane workgroups and at most 12 waves resident per CU (more waves in flight lower the achieved HBM
+// bandwidth by ~15 %); the 16-bit formats with the 4-cells-per-lane kernel (aligned 8-byte accesses); rows that are not a
+// multiple of 4 cells fall back to 2 (FP16S) or 1 (FP16C) cells per lane.  Heavier collision variants (TRT, subgrid,
+// field output) want more waves, which the search below finds on the running lattice.
+static void default_geometry(const lbmhip_domain* d, bool fields_only, int* V_out, int* blocks_per_cu_out) {
 	const bool small = d->cfg.velocity_set == 9u || d->cfg.velocity_set == 15u;
 	const bool half = d->cfg.storage != LBMHIP_FP32;
 	int V = fields_only ? 1 : d->cells_per_thread;
@@ -343,17 +360,35 @@ static int launch_collide_planes(lbmhip_domain* d, uint64_t t, float fx, float f
 	if (small) V = 1;
 	while (V > 1 && d->cfg.Nx%(uint32_t)V != 0u) V /= 2; // vector accesses need rows that are whole vectors
 	if (V == 2 && d->cells_per_thread == 0 && d->cfg.storage == LBMHIP_FP16C) V = 1;
+	int blocks_per_cu = d->blocks_per_cu;
+	if (blocks_per_cu < 0) {
+		if (fields_only) blocks_per_cu = 0;
+		else if (!half) blocks_per_cu = d->cfg.velocity_set == 27u ? 4 : 3;
+		else blocks_per_cu = (d->cfg.storage == LBMHIP_FP16S && d->cfg.velocity_set == 19u && V == 4) ? 7 : 0;
+	}
+	*V_out = V; *blocks_per_cu_out = blocks_per_cu;
+}
+
+// the geometries worth trying for this domain (blocks_per_cu counts 256-lane workgroups)
+static void build_candidates(lbmhip_domain* d) {
+	const bool small = d->cfg.velocity_set == 9u || d->cfg.velocity_set == 15u;
+	const bool half = d->cfg.storage != LBMHIP_FP32;
+	d->ncand = 0;
+	auto add = [&](int V, std::initializer_list<int> caps) {
+		if (V > 1 && (small || d->cfg.Nx%(uint32_t)V != 0u)) return;
+		for (int c : caps) if (d->ncand < 24) { d->cand[d->ncand].V = V; d->cand[d->ncand].blocks_per_cu = c; d->cand[d->ncand].ms = 1e30f; d->ncand++; }
+	};
+	if (!half) { add(1, {2, 3, 4, 5, 0}); add(2, {2, 3, 4, 0}); }
+	else { add(4, {0, 4, 5, 6, 7, 8}); add(1, {0, 4, 8}); if (d->cfg.storage == LBMHIP_FP16S) add(2, {0}); }
+}
+
+static int launch_collide_geometry(lbmhip_domain* d, const Args& base, int V, int blocks_per_cu, uint32_t z0, uint32_t z1, bool fields_only) {
 	const uint32_t lanes_per_row = (d->cfg.Nx+(uint32_t)V-1u)/(uint32_t)V;
 	uint32_t block = d->block ? (uint32_t)d->block : 256u;
 	const uint32_t need = (lanes_per_row+63u)/64u*64u;
 	if (block > need) block = need;
-	int blocks_per_cu = d->blocks_per_cu;
-	if (blocks_per_cu < 0) {
-		if (fields_only) blocks_per_cu = 0;
-		else if (!half) blocks_per_cu = (int)std::max(1u, (d->cfg.velocity_set == 27u ? 16u : 12u)/(block/64u));
-		else blocks_per_cu = (d->cfg.storage == LBMHIP_FP16S && d->cfg.velocity_set == 19u && V == 4) ? 7 : 0;
-	}
-	Args a = make_args(d, t, fx, fy, fz);
+	if (blocks_per_cu > 0) blocks_per_cu = std::max(1, blocks_per_cu*256/(int)block); // the cap is quoted for 256-lane workgroups
+	Args a = base;
 	a.z0 = z0; a.z1 = z1;
 	a.xchunks = (lanes_per_row+block-1u)/block;
 	// one grid dimension carries at most 2^32-1 work-items: x-chunks and y go to grid.x, lattice planes to grid.y
@@ -361,10 +396,51 @@ static int launch_collide_planes(lbmhip_domain* d, uint64_t t, float fx, float f
 	NEED(blocks_x*block < 0xFFFFFFFFull && (z1-z0) <= 65535u, "lattice too large for one launch (%llu x %u workgroups)", (unsigned long long)blocks_x, z1-z0);
 	collide_launch_fn fn = find_collide(d, V, fields_only);
 	NEED(fn, "no compiled kernel for D?Q%u storage %u collision %u", d->cfg.velocity_set, d->cfg.storage, d->cfg.collision);
-	DeviceGuard g(d->cfg.device);
 	// dynamic LDS is not used by the kernel; reserving it caps the workgroups resident per CU (160 KiB LDS per CU)
 	const uint32_t lds = blocks_per_cu > 0 ? ((160u*1024u/(uint32_t)blocks_per_cu)&~255u) : 0u;
 	HIP_TRY(fn(a, dim3((uint32_t)blocks_x, z1-z0), dim3(block), lds, d->stream));
+	return 0;
+}
+
+static int launch_collide_planes(lbmhip_domain* d, uint64_t t, float fx, float fy, float fz, uint32_t z0, uint32_t z1, bool fields_only) {
+	const uint32_t hz = d->cfg.Dz > 1u;
+	if (z0 < hz) z0 = hz;
+	if (z1 > d->cfg.Nz-hz) z1 = d->cfg.Nz-hz;
+	if (z0 >= z1) return 0;
+	const Args a = make_args(d, t, fx, fy, fz);
+	DeviceGuard g(d->cfg.device);
+	int V, blocks_per_cu;
+	default_geometry(d, fields_only, &V, &blocks_per_cu);
+	const bool user_set = d->cells_per_thread != 0 || d->blocks_per_cu >= 0 || d->block != 0;
+	if (fields_only || user_set || !d->autotune) return launch_collide_geometry(d, a, V, blocks_per_cu, z0, z1, fields_only);
+	if (d->tuned) return launch_collide_geometry(d, a, d->tuned_V, d->tuned_blocks_per_cu, z0, z1, false);
+
+	// Geometry search: every full-lattice launch of the first 2*ncand steps runs one candidate between two events; all
+	// candidates compute the same bits, so the search is invisible in the results.  Lattices too small to time are left alone.
+	const uint64_t cells = (uint64_t)d->cfg.Nx*d->cfg.Ny*(z1-z0);
+	const bool searchable = d->N >= (1ull<<21) && 4u*(uint64_t)(z1-z0) >= 3u*(uint64_t)(d->cfg.Nz-2u*hz) && cells > 0u;
+	if (!searchable) return launch_collide_geometry(d, a, V, blocks_per_cu, z0, z1, false);
+	if (d->ncand == 0) build_candidates(d);
+	if (d->tune_pending >= 0) { // collect the previous candidate's time
+		float ms = 0.0f;
+		HIP_TRY(hipEventSynchronize(d->ev_tune1));
+		HIP_TRY(hipEventElapsedTime(&ms, d->ev_tune0, d->ev_tune1));
+		if (ms < d->cand[d->tune_pending].ms) d->cand[d->tune_pending].ms = ms;
+		d->tune_pending = -1;
+		if (d->tune_launches >= 2*d->ncand) {
+			int best = 0;
+			for (int k = 1; k < d->ncand; k++) if (d->cand[k].ms < d->cand[best].ms) best = k;
+			d->tuned_V = d->cand[best].V; d->tuned_blocks_per_cu = d->cand[best].blocks_per_cu; d->tuned = 1;
+			return launch_collide_geometry(d, a, d->tuned_V, d->tuned_blocks_per_cu, z0, z1, false);
+		}
+	}
+	const int k = d->tune_launches%d->ncand;
+	HIP_TRY(hipEventRecord(d->ev_tune0, d->stream));
+	const int status = launch_collide_geometry(d, a, d->cand[k].V, d->cand[k].blocks_per_cu, z0, z1, false);
+	if (status) return status;
+	HIP_TRY(hipEventRecord(d->ev_tune1, d->stream));
+	d->tune_pending = k;
+	d->tune_launches++;
 	return 0;
 }
 

@@ -209,6 +209,12 @@ class LBM:
     def bytes_per_cell_device(self):
         return self._L.lbmhip_bytes_per_cell_device(self.Q, STORAGE[self.storage], feature_mask(self.features))
 
+    def get_tuning(self, key):
+        """Launch setting of the first domain ("cells_per_thread", "blocks_per_cu", "block", "autotune", "tuned")."""
+        v = C.c_int()
+        check(self._L.lbmhip_get_tuning(self.domains[0].h, key.encode(), C.byref(v)))
+        return v.value
+
     def set_tuning(self, key, value):
         for dom in self.domains:
             check(self._L.lbmhip_set_tuning(dom.h, key.encode(), int(value)))

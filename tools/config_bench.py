@@ -1,0 +1,87 @@
+"""Diagnostic: single-GPU stream_collide rate of the five benchmark configurations (GPU needed).  The lattices start at
+rest (the rate does not depend on the field data); solids are an extruded pillar mask uploaded plane by plane, so no
+host copy of the big lattices is ever made.  usage: python tools/config_bench.py [--sweep] [names...]   (--sweep also tries every launch geometry)"""
+import ctypes as C
+import sys
+
+import numpy as np
+
+sys.path.insert(0, ".")
+import cfd_amd
+from cfd_amd import lbm as L
+from cfd_amd import setups
+
+F = L.FEATURES
+CONFIGS = {
+    "cavity128_fp32_mb": dict(N=(128, 128, 128), Q=19, st="FP32", coll="SRT", feat=F["MOVING_BOUNDARIES"], walls=True),
+    "tgv512_fp32": dict(N=(512, 512, 512), Q=19, st="FP32", coll="SRT", feat=0),
+    "tgv512_fp32_trt": dict(N=(512, 512, 512), Q=19, st="FP32", coll="TRT", feat=0),
+    "tgv512_fp32_sgs": dict(N=(512, 512, 512), Q=19, st="FP32", coll="SRT", feat=F["SUBGRID"]),
+    "gui512_fp16s": dict(N=(512, 512, 512), Q=19, st="FP16S", coll="SRT", feat=F["UPDATE_FIELDS"] | F["VOLUME_FORCE"] | F["EQUILIBRIUM_BOUNDARIES"] | F["SUBGRID"], mask=True, f=(0.0, 0.0, 1e-5)),
+    "capacity1600_fp16s": dict(N=(1600, 1600, 1600), Q=19, st="FP16S", coll="SRT", feat=0),
+    "channel512_trt_sgs": dict(N=(512, 512, 512), Q=19, st="FP32", coll="TRT", feat=F["VOLUME_FORCE"] | F["SUBGRID"], mask=True, f=(2e-4, 0.0, 0.0)),
+    "channel512_trt_sgs_fp16s": dict(N=(512, 512, 512), Q=19, st="FP16S", coll="TRT", feat=F["VOLUME_FORCE"] | F["SUBGRID"], mask=True, f=(2e-4, 0.0, 0.0)),
+    "q27_fp16c_force_slab": dict(N=(2048, 2048, 256), Q=27, st="FP16C", coll="SRT", feat=F["FORCE_FIELD"] | F["VOLUME_FORCE"], mask=True, f=(1e-5, 0.0, 0.0)),
+}
+
+
+def run(name, c):
+    lib = cfd_amd.lib()
+    Nx, Ny, Nz = c["N"]
+    cfg = L.Config(Nx, Ny, Nz, 1, 1, 1, 0, 0, 0, c["Q"], L.STORAGE[c["st"]], L.COLLISION[c["coll"]], c["feat"], 0.01, 0)
+    dom = L.Domain(cfg)
+    try:
+        if c.get("mask") or c.get("walls"):
+            plane = np.zeros((Ny, Nx), dtype=np.uint8)
+            if c.get("mask"):
+                plane[...] = setups.obstacle_mask(Nx, Ny, seed=42)
+                plane[0] = plane[-1] = 1
+            else:
+                plane[0] = plane[-1] = 1; plane[:, 0] = plane[:, -1] = 1
+            for z in range(Nz):
+                p = np.ones_like(plane) if (c.get("walls") and z in (0, Nz - 1)) else plane
+                dom.upload(L.FIELD_FLAGS, np.ascontiguousarray(p), offset=z * Nx * Ny)
+            if c.get("walls"):  # moving lid
+                lid = np.full(Nx * Ny, 0.1, dtype=np.float32)
+                dom.upload(L.FIELD_U, lid, offset=(dom.N + (Nz - 1) * Nx * Ny) * 4)
+        L.check(lib.lbmhip_initialize(dom.h))
+        f = c.get("f", (0.0, 0.0, 0.0))
+        step = lambda t: L.check(lib.lbmhip_stream_collide(dom.h, C.c_uint64(t), C.c_float(f[0]), C.c_float(f[1]), C.c_float(f[2])))
+        t = [0]
+        B = lib.lbmhip_bandwidth_bytes_per_cell(c["Q"], L.STORAGE[c["st"]], c["feat"])
+
+        def measure(label, warm=6):
+            for _ in range(warm):
+                step(t[0]); t[0] += 1
+            n = max(10, min(400, int(4e9 / dom.N)))
+            ms = C.c_float()
+            L.check(lib.lbmhip_timer_start(dom.h))
+            for _ in range(n):
+                step(t[0]); t[0] += 1
+            L.check(lib.lbmhip_timer_stop(dom.h, C.byref(ms)))
+            per = ms.value / n
+            return per, "%-26s %5dx%4dx%4d  %-22s %.3f ms/step  %7.0f MLUPs/s  %4d B/cell  %5.0f GB/s (%.1f%% of 8 TB/s)" % (
+                name, Nx, Ny, Nz, label, per, dom.N / per / 1e3, B, B * dom.N / per / 1e6, B * dom.N / per / 1e6 / 80)
+
+        per, line = measure("default", warm=52)  # covers the library's geometry search
+        got = {}
+        for key in ("tuned", "cells_per_thread", "blocks_per_cu"):
+            v = C.c_int(); L.check(lib.lbmhip_get_tuning(dom.h, key.encode(), C.byref(v))); got[key] = v.value
+        print(line + "  [tuned=%(tuned)d V=%(cells_per_thread)d blocks/CU<=%(blocks_per_cu)d]" % got, flush=True)
+        if SWEEP:
+            res = []
+            for v in (1, 2, 4):
+                for k in (0, 2, 3, 4, 5, 6, 7, 8):
+                    for key, val in (("cells_per_thread", v), ("blocks_per_cu", k)):
+                        L.check(lib.lbmhip_set_tuning(dom.h, key.encode(), val))
+                    res.append(measure("V=%d blocks/CU<=%d" % (v, k)))
+            for per, line in sorted(res)[:4]:
+                print("   " + line, flush=True)
+    finally:
+        dom.close()
+
+
+SWEEP = "--sweep" in sys.argv
+names = [a for a in sys.argv[1:] if not a.startswith("--")]
+for name in (names or list(CONFIGS)):
+    run(name, CONFIGS[name])

@@ -3,7 +3,7 @@
 # PMC passes (FETCH_SIZE and WRITE_SIZE cannot share a pass).  Results land in gpurun_out/prof_<tag>/.
 set -e
 TAG=${1:-r01}
-ARGS=${2:-"--steps 20 --warmup 5 --no-cpu-baseline"}
+ARGS=${2:-"--no-cpu-baseline"}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
 cd /tmp
