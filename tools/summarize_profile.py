@@ -16,13 +16,14 @@ src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
-stats = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))[0]
+newest = lambda pattern: max(glob.glob(pattern), key=os.path.getmtime)  # gpurun merges runs: older files of the same tag may remain
+stats = newest(os.path.join(src, "stats", "*", "*kernel_stats.csv"))
 shutil.copy(stats, os.path.join(dst, "%s_kernel_stats.csv" % tag))
 bench_line = re.findall(r'\{"metric.*\}', open(os.path.join(src, "stats.log")).read())
 bench = json.loads(bench_line[0]) if bench_line else {}
 
 counters = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(os.path.join(src, "pmc_*", "*", "*counter_collection.csv")):
+for f in [newest(os.path.join(d, "*", "*counter_collection.csv")) for d in glob.glob(os.path.join(src, "pmc_*")) if os.path.isdir(d)]:
     for r in csv.DictReader(open(f)):
         counters[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 rows = []
