@@ -273,6 +273,11 @@ __global__ __launch_bounds__(256) void k_collide_wide(const Args a) {
 	});
 
 	// ---- the V cells, one after the other
+	typedef float ovec __attribute__((ext_vector_type(V)));
+	ovec out[4]; // rho, ux, uy, uz of the V cells (UPDATE_FIELDS)
+	bool wf[V];
+#pragma unroll
+	for (int v = 0; v < V; v++) wf[v] = false;
 #pragma unroll
 	for (int v = 0; v < V; v++) {
 		if (active[v]) {
@@ -297,9 +302,8 @@ __global__ __launch_bounds__(256) void k_collide_wide(const Args a) {
 				});
 			}
 			float rhon, uxn, uyn, uzn;
-			bool wf = false;
-			collide<Q, COLL, false>(f, feat, bo, a, n, rhon, uxn, uyn, uzn, wf);
-			if (feat(F_UPDATE_FIELDS) && wf) { a.rho[n] = rhon; a.u[n] = uxn; a.u[a.N+n] = uyn; a.u[2ull*a.N+n] = uzn; } // kernel.cpp:1581-1591
+			collide<Q, COLL, false>(f, feat, bo, a, n, rhon, uxn, uyn, uzn, wf[v]);
+			if (feat(F_UPDATE_FIELDS)) { out[0][v] = rhon; out[1][v] = uxn; out[2][v] = uyn; out[3][v] = uzn; }
 			// streaming part 1 in registers: the slot that held f[i] receives f[i+1] and vice versa (kernel.cpp:1339-1345)
 			d[0][v] = S::encode(f[0]);
 			static_for<1, Q, 2>([&](auto I) {
@@ -309,6 +313,26 @@ __global__ __launch_bounds__(256) void k_collide_wide(const Args a) {
 			});
 		}
 		__builtin_amdgcn_sched_barrier(0); // keep the cells apart: interleaving them multiplies the live registers
+	}
+
+	// ---- rho/u output (kernel.cpp:1581-1591): one aligned vector per field when all V cells write, else cell by cell
+	if (feat(F_UPDATE_FIELDS)) {
+		bool all = true, some = false;
+#pragma unroll
+		for (int v = 0; v < V; v++) { all = all && wf[v]; some = some || wf[v]; }
+		const uint64_t n0 = row0+x;
+		if (all) {
+			*reinterpret_cast<ovec*>(a.rho+n0) = out[0];
+			*reinterpret_cast<ovec*>(a.u+n0) = out[1];
+			*reinterpret_cast<ovec*>(a.u+a.N+n0) = out[2];
+			*reinterpret_cast<ovec*>(a.u+2ull*a.N+n0) = out[3];
+		} else if (some) {
+#pragma unroll
+			for (int v = 0; v < V; v++) if (wf[v]) {
+				const uint64_t n = n0+(uint32_t)v;
+				a.rho[n] = out[0][v]; a.u[n] = out[1][v]; a.u[a.N+n] = out[2][v]; a.u[2ull*a.N+n] = out[3][v];
+			}
+		}
 	}
 
 	// ---- streaming part 1 (kernel.cpp:1339-1345): write every vector back to where it came from
