@@ -147,3 +147,20 @@ def test_ragged_shapes_and_halos(gpu, name):
         assert np.isfinite(a.u).all()
     finally:
         a.close()
+
+
+def test_geometry_search_is_invisible_in_the_results(gpu):
+    """The library tries its launch geometries on the first full-lattice launches of a large enough lattice and keeps the
+    fastest; a run with the search and a run with fixed defaults must agree bit for bit, and the search must finish."""
+    kw = dict(N=(128, 128, 128), nu=0.01, storage="FP16S", collision="TRT", features=("VOLUME_FORCE", "SUBGRID"), f=(1e-4, 0.0, 0.0))
+    from tests import cases as CS
+    with cfd_amd.LBM(**kw) as a, cfd_amd.LBM(**kw) as b:
+        b.set_tuning("autotune", 0)
+        CS._channel_setup(a); CS._channel_setup(b)
+        assert a.get_tuning("autotune") == 1 and b.get_tuning("autotune") == 0
+        a.run(60); b.run(60)
+        assert a.get_tuning("tuned") == 1 and b.get_tuning("tuned") == 0
+        assert a.get_tuning("cells_per_thread") in (1, 2, 4) and 0 <= a.get_tuning("blocks_per_cu") <= 8
+        a.read_from_device(); b.read_from_device()
+        assert np.array_equal(a.u.view(np.uint32), b.u.view(np.uint32)) and np.array_equal(a.rho.view(np.uint32), b.rho.view(np.uint32))
+        assert np.array_equal(a.domains[0].download_fi(), b.domains[0].download_fi())
