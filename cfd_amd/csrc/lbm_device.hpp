@@ -30,6 +30,7 @@ struct Args {
 	uint32_t features;   // run-time feature mask (used by kernels instantiated with FEAT < 0)
 	uint32_t xchunks;    // thread blocks per lattice row
 	float fx, fy, fz, w;
+	float tau0, wm;      // 1/w and the TRT rate 1/(0.1875/(1/w-0.5)+0.5) of the lattice viscosity, evaluated once on the host in float
 };
 
 // ---------------------------------------------------------------------------------------------- static_for
@@ -182,7 +183,7 @@ __device__ __forceinline__ void collide(float* f, const Feat feat, const uint8_t
 	f_eq<Q>(rhon, uxn, uyn, uzn, feq);
 	float w = a.w;
 	if (feat(F_SUBGRID)) { // Smagorinsky-Lilly (kernel.cpp:1597-1611)
-		const float tau0 = 1.0f/w;
+		const float tau0 = a.tau0; // = 1/w (kernel.cpp:1598)
 		float Hxx = 0.0f, Hyy = 0.0f, Hzz = 0.0f, Hxy = 0.0f, Hxz = 0.0f, Hyz = 0.0f;
 		static_for<1, Q, 1>([&](auto I) {
 			constexpr int i = I, cx = dir<Q>(i,0), cy = dir<Q>(i,1), cz = dir<Q>(i,2);
@@ -208,7 +209,7 @@ __device__ __forceinline__ void collide(float* f, const Feat feat, const uint8_t
 			f[i] = eq_cell ? feq[i] : fmaf(omw, f[i], fmaf(w, feq[i], Fin));
 		});
 	} else { // TRT (kernel.cpp:1623-1651)
-		const float wp = w, wm = 1.0f/(0.1875f/(1.0f/w-0.5f)+0.5f);
+		const float wp = w, wm = feat(F_SUBGRID) ? 1.0f/(0.1875f/(1.0f/w-0.5f)+0.5f) : a.wm; // without subgrid w is the lattice constant
 		const float c_taup = fmaf(wp, -0.25f, 0.5f), c_taum = fmaf(wm, -0.25f, 0.5f), hwp = 0.5f*wp, hwm = 0.5f*wm;
 		{
 			const float Fin0 = force ? forcing_term<Q, 0>(uxn, uyn, uzn, fxn, fyn, fzn, uF) : 0.0f;

@@ -82,6 +82,7 @@ static Args make_args(const lbmhip_domain* d, uint64_t t, float fx, float fy, fl
 	a.z0 = a.hz; a.z1 = d->cfg.Nz-a.hz;
 	a.odd = (uint32_t)(t&1ull); a.features = d->cfg.features; a.xchunks = 1u;
 	a.fx = fx; a.fy = fy; a.fz = fz; a.w = d->w;
+	a.tau0 = 1.0f/d->w; a.wm = 1.0f/(0.1875f/(1.0f/d->w-0.5f)+0.5f); // kernel.cpp:1598, 1624 (IEEE float division, as on the device)
 	return a;
 }
 
