@@ -56,7 +56,7 @@ def measured_traffic(workload):
         return None
 
 
-TUNE_STEPS = 52
+TUNE_STEPS = 100
 
 
 def main():

@@ -38,8 +38,8 @@ struct lbmhip_domain {
 	hipEvent_t ev_start, ev_stop, ev_packed, ev_copied;
 	int cells_per_thread, block, blocks_per_cu;
 	// launch-geometry search over the first full-lattice stream_collide launches (results do not depend on the geometry)
-	struct { int V, blocks_per_cu; float ms; } cand[24];
-	int ncand, tune_launches, tune_pending, autotune, tuned, tuned_V, tuned_blocks_per_cu;
+	struct { int V, blocks_per_cu, block; float ms; } cand[48];
+	int ncand, tune_launches, tune_pending, autotune, tuned, tuned_V, tuned_blocks_per_cu, tuned_block;
 	hipEvent_t ev_tune0, ev_tune1;
 	void* partial; // per-workgroup partial sums of the object_* reductions (kObjectSumBlocks float4)
 	float w;
@@ -327,7 +327,7 @@ int lbmhip_get_tuning(lbmhip_domain* d, const char* key, int* value) {
 	NEED(d && key && value, "null argument");
 	if (!strcmp(key, "cells_per_thread")) { *value = d->tuned ? d->tuned_V : d->cells_per_thread; return 0; }
 	if (!strcmp(key, "blocks_per_cu")) { *value = d->tuned ? d->tuned_blocks_per_cu : d->blocks_per_cu; return 0; }
-	if (!strcmp(key, "block")) { *value = d->block; return 0; }
+	if (!strcmp(key, "block")) { *value = d->tuned ? d->tuned_block : d->block; return 0; }
 	if (!strcmp(key, "autotune")) { *value = d->autotune; return 0; }
 	if (!strcmp(key, "tuned")) { *value = d->tuned; return 0; }
 	return fail("unknown tuning key '%s'", key);
@@ -375,17 +375,20 @@ static void build_candidates(lbmhip_domain* d) {
 	const bool small = d->cfg.velocity_set == 9u || d->cfg.velocity_set == 15u;
 	const bool half = d->cfg.storage != LBMHIP_FP32;
 	d->ncand = 0;
-	auto add = [&](int V, std::initializer_list<int> caps) {
+	auto add = [&](int V, std::initializer_list<int> caps, std::initializer_list<int> ragged_caps) {
 		if (V > 1 && (small || d->cfg.Nx%(uint32_t)V != 0u)) return;
-		for (int c : caps) if (d->ncand < 24) { d->cand[d->ncand].V = V; d->cand[d->ncand].blocks_per_cu = c; d->cand[d->ncand].ms = 1e30f; d->ncand++; }
+		auto push = [&](int c, int block) { if (d->ncand < 48) { d->cand[d->ncand].V = V; d->cand[d->ncand].blocks_per_cu = c; d->cand[d->ncand].block = block; d->cand[d->ncand].ms = 1e30f; d->ncand++; } };
+		for (int c : caps) push(c, 0);
+		// rows that do not fill whole 256-lane workgroups: smaller workgroups waste fewer lanes at the row end
+		if ((d->cfg.Nx/(uint32_t)V)%256u != 0u && d->cfg.Nx/(uint32_t)V > 128u) for (int c : ragged_caps) { push(c, 128); push(c, 64); }
 	};
-	if (!half) { add(1, {2, 3, 4, 5, 0}); add(2, {2, 3, 4, 0}); }
-	else { add(4, {0, 4, 5, 6, 7, 8}); add(1, {0, 4, 8}); if (d->cfg.storage == LBMHIP_FP16S) add(2, {0}); }
+	if (!half) { add(1, {2, 3, 4, 5, 0}, {3, 0}); add(2, {2, 3, 4, 0}, {2, 3}); add(4, {0, 5}, {}); }
+	else { add(4, {0, 4, 5, 6, 7, 8}, {0, 4}); add(1, {0, 4, 8}, {8}); if (d->cfg.storage == LBMHIP_FP16S) add(2, {0}, {6}); }
 }
 
-static int launch_collide_geometry(lbmhip_domain* d, const Args& base, int V, int blocks_per_cu, uint32_t z0, uint32_t z1, bool fields_only) {
+static int launch_collide_geometry(lbmhip_domain* d, const Args& base, int V, int blocks_per_cu, int block_lanes, uint32_t z0, uint32_t z1, bool fields_only) {
 	const uint32_t lanes_per_row = (d->cfg.Nx+(uint32_t)V-1u)/(uint32_t)V;
-	uint32_t block = d->block ? (uint32_t)d->block : 256u;
+	uint32_t block = block_lanes ? (uint32_t)block_lanes : 256u;
 	const uint32_t need = (lanes_per_row+63u)/64u*64u;
 	if (block > need) block = need;
 	if (blocks_per_cu > 0) blocks_per_cu = std::max(1, blocks_per_cu*256/(int)block); // the cap is quoted for 256-lane workgroups
@@ -413,14 +416,14 @@ static int launch_collide_planes(lbmhip_domain* d, uint64_t t, float fx, float f
 	int V, blocks_per_cu;
 	default_geometry(d, fields_only, &V, &blocks_per_cu);
 	const bool user_set = d->cells_per_thread != 0 || d->blocks_per_cu >= 0 || d->block != 0;
-	if (fields_only || user_set || !d->autotune) return launch_collide_geometry(d, a, V, blocks_per_cu, z0, z1, fields_only);
-	if (d->tuned) return launch_collide_geometry(d, a, d->tuned_V, d->tuned_blocks_per_cu, z0, z1, false);
+	if (fields_only || user_set || !d->autotune) return launch_collide_geometry(d, a, V, blocks_per_cu, d->block, z0, z1, fields_only);
+	if (d->tuned) return launch_collide_geometry(d, a, d->tuned_V, d->tuned_blocks_per_cu, d->tuned_block, z0, z1, false);
 
 	// Geometry search: every full-lattice launch of the first 2*ncand steps runs one candidate between two events; all
 	// candidates compute the same bits, so the search is invisible in the results.  Lattices too small to time are left alone.
 	const uint64_t cells = (uint64_t)d->cfg.Nx*d->cfg.Ny*(z1-z0);
 	const bool searchable = d->N >= (1ull<<21) && 4u*(uint64_t)(z1-z0) >= 3u*(uint64_t)(d->cfg.Nz-2u*hz) && cells > 0u;
-	if (!searchable) return launch_collide_geometry(d, a, V, blocks_per_cu, z0, z1, false);
+	if (!searchable) return launch_collide_geometry(d, a, V, blocks_per_cu, 0, z0, z1, false);
 	if (d->ncand == 0) build_candidates(d);
 	if (d->tune_pending >= 0) { // collect the previous candidate's time
 		float ms = 0.0f;
@@ -431,13 +434,13 @@ static int launch_collide_planes(lbmhip_domain* d, uint64_t t, float fx, float f
 		if (d->tune_launches >= 2*d->ncand) {
 			int best = 0;
 			for (int k = 1; k < d->ncand; k++) if (d->cand[k].ms < d->cand[best].ms) best = k;
-			d->tuned_V = d->cand[best].V; d->tuned_blocks_per_cu = d->cand[best].blocks_per_cu; d->tuned = 1;
-			return launch_collide_geometry(d, a, d->tuned_V, d->tuned_blocks_per_cu, z0, z1, false);
+			d->tuned_V = d->cand[best].V; d->tuned_blocks_per_cu = d->cand[best].blocks_per_cu; d->tuned_block = d->cand[best].block; d->tuned = 1;
+			return launch_collide_geometry(d, a, d->tuned_V, d->tuned_blocks_per_cu, d->tuned_block, z0, z1, false);
 		}
 	}
 	const int k = d->tune_launches%d->ncand;
 	HIP_TRY(hipEventRecord(d->ev_tune0, d->stream));
-	const int status = launch_collide_geometry(d, a, d->cand[k].V, d->cand[k].blocks_per_cu, z0, z1, false);
+	const int status = launch_collide_geometry(d, a, d->cand[k].V, d->cand[k].blocks_per_cu, d->cand[k].block, z0, z1, false);
 	if (status) return status;
 	HIP_TRY(hipEventRecord(d->ev_tune1, d->stream));
 	d->tune_pending = k;

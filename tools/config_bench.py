@@ -18,6 +18,12 @@ CONFIGS = {
     "tgv512_fp32_trt": dict(N=(512, 512, 512), Q=19, st="FP32", coll="TRT", feat=0),
     "tgv512_fp32_sgs": dict(N=(512, 512, 512), Q=19, st="FP32", coll="SRT", feat=F["SUBGRID"]),
     "gui512_fp16s": dict(N=(512, 512, 512), Q=19, st="FP16S", coll="SRT", feat=F["UPDATE_FIELDS"] | F["VOLUME_FORCE"] | F["EQUILIBRIUM_BOUNDARIES"] | F["SUBGRID"], mask=True, f=(0.0, 0.0, 1e-5)),
+    "fp16s_1600x512x512": dict(N=(1600, 512, 512), Q=19, st="FP16S", coll="SRT", feat=0),
+    "fp16s_1024": dict(N=(1024, 1024, 1024), Q=19, st="FP16S", coll="SRT", feat=0),
+    "fp16s_768": dict(N=(768, 768, 768), Q=19, st="FP16S", coll="SRT", feat=0),
+    "fp16s_512x1600x512": dict(N=(512, 1600, 512), Q=19, st="FP16S", coll="SRT", feat=0),
+    "fp32_1024": dict(N=(1024, 1024, 1024), Q=19, st="FP32", coll="SRT", feat=0),
+    "fp32_1600x512x512": dict(N=(1600, 512, 512), Q=19, st="FP32", coll="SRT", feat=0),
     "capacity1600_fp16s": dict(N=(1600, 1600, 1600), Q=19, st="FP16S", coll="SRT", feat=0),
     "channel512_trt_sgs": dict(N=(512, 512, 512), Q=19, st="FP32", coll="TRT", feat=F["VOLUME_FORCE"] | F["SUBGRID"], mask=True, f=(2e-4, 0.0, 0.0)),
     "channel512_trt_sgs_fp16s": dict(N=(512, 512, 512), Q=19, st="FP16S", coll="TRT", feat=F["VOLUME_FORCE"] | F["SUBGRID"], mask=True, f=(2e-4, 0.0, 0.0)),
@@ -63,25 +69,27 @@ def run(name, c):
             return per, "%-26s %5dx%4dx%4d  %-22s %.3f ms/step  %7.0f MLUPs/s  %4d B/cell  %5.0f GB/s (%.1f%% of 8 TB/s)" % (
                 name, Nx, Ny, Nz, label, per, dom.N / per / 1e3, B, B * dom.N / per / 1e6, B * dom.N / per / 1e6 / 80)
 
-        per, line = measure("default", warm=52)  # covers the library's geometry search
+        per, line = measure("default", warm=100)  # covers the library's geometry search
         got = {}
-        for key in ("tuned", "cells_per_thread", "blocks_per_cu"):
+        for key in ("tuned", "cells_per_thread", "blocks_per_cu", "block"):
             v = C.c_int(); L.check(lib.lbmhip_get_tuning(dom.h, key.encode(), C.byref(v))); got[key] = v.value
-        print(line + "  [tuned=%(tuned)d V=%(cells_per_thread)d blocks/CU<=%(blocks_per_cu)d]" % got, flush=True)
+        print(line + "  [tuned=%(tuned)d V=%(cells_per_thread)d blocks/CU<=%(blocks_per_cu)d block=%(block)d]" % got, flush=True)
         if SWEEP:
             res = []
-            for v in (1, 2, 4):
-                for k in (0, 2, 3, 4, 5, 6, 7, 8):
-                    for key, val in (("cells_per_thread", v), ("blocks_per_cu", k)):
-                        L.check(lib.lbmhip_set_tuning(dom.h, key.encode(), val))
-                    res.append(measure("V=%d blocks/CU<=%d" % (v, k)))
-            for per, line in sorted(res)[:4]:
+            for b in BLOCKS:
+                for v in (1, 2, 4):
+                    for k in (0, 2, 3, 4, 5, 6, 7, 8):
+                        for key, val in (("cells_per_thread", v), ("blocks_per_cu", k), ("block", b)):
+                            L.check(lib.lbmhip_set_tuning(dom.h, key.encode(), val))
+                        res.append(measure("V=%d blocks/CU<=%d block=%d" % (v, k, b or 256)))
+            for per, line in sorted(res)[:6]:
                 print("   " + line, flush=True)
     finally:
         dom.close()
 
 
-SWEEP = "--sweep" in sys.argv
+SWEEP = "--sweep" in sys.argv or "--sweep-blocks" in sys.argv
+BLOCKS = (0, 192, 128, 64) if "--sweep-blocks" in sys.argv else (0,)
 names = [a for a in sys.argv[1:] if not a.startswith("--")]
 for name in (names or list(CONFIGS)):
     run(name, CONFIGS[name])

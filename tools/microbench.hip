@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include <algorithm>
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
@@ -165,6 +166,7 @@ template <class F> float time_ms(F launch, int reps) {
 	return ms/reps;
 }
 template <int V, int MODE, bool NT> void run(float* fi, size_t N, unsigned n, unsigned block, size_t pad, unsigned blocks_per_cu = 0) {
+	float* fo = fi; (void)fo;
 	const unsigned lanes = n/V, b = block > lanes ? lanes : block, xchunks = (lanes+b-1)/b;
 	const unsigned lds = blocks_per_cu ? (160u*1024u/blocks_per_cu)&~255u : 0u; // dynamic LDS only throttles residency
 	const float ms = time_ms([&]() { hipLaunchKernelGGL((k_rmw<V, MODE, NT>), dim3(xchunks*n*n), dim3(b), lds, 0, fi, fi, N+pad, n, n, n, xchunks, 0.999f); }, 10);
@@ -198,6 +200,11 @@ int main(int argc, char** argv) {
 		CHECK(hipMemset(fi, 0, (N+padmax)*19*sizeof(float)));
 	}
 	CHECK(hipMemset(fi, 0, (N+padmax)*19*sizeof(float)));
+	if (argc > 3 && !strcmp(argv[3], "pad")) { // stream-stride padding sweep for the FP32 one-cell-per-lane pattern
+		for (size_t pad : {(size_t)0, (size_t)32, (size_t)64, (size_t)128, (size_t)256, (size_t)512, (size_t)1024, (size_t)2048, (size_t)4096, (size_t)4160, (size_t)8192, (size_t)8256, (size_t)16384, (size_t)16448, (size_t)65536, (size_t)65600, (size_t)262144, (size_t)262208, (size_t)524288, (size_t)1048576-64})
+			for (unsigned k : {2u, 3u}) run<1, 1, false>(fi, N, n, 256u, pad, k);
+		return 0;
+	}
 	if (argc > 3) { // third argument: 16-bit stream sweep only
 		auto sweep16 = [&](auto kern, int V, int shift, int work) {
 			for (unsigned k : {0u, 2u, 3u, 4u, 6u}) {

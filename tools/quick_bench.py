@@ -16,7 +16,7 @@ L = cfd_amd.lib()
 for storage in ("FP32", "FP16S", "FP16C"):
     with cfd_amd.LBM((n, n, n), 0.01, storage=storage, Q=Q) as lbm:
         setups.taylor_green(lbm)
-        lbm.run(52)  # covers the library's geometry search
+        lbm.run(100)  # covers the library's geometry search
         dom = lbm.domains[0]
         best = 1e9
         for _ in range(3):
