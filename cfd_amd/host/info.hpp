@@ -11,6 +11,8 @@ struct Info {
 	double runtime_lbm_timestep_smooth = 1.0;   // exponentially smoothed step time
 	ulong steps = max_ulong, steps_last = 0ull;
 	std::mutex allow_printing;
+	Clock since_start;                          // wall clock since the program started (runtime_total of the reference)
+	double runtime_total() { return since_start.stop(); }
 	void append(const ulong steps, const ulong total_steps, const ulong t) { (void)total_steps; this->steps = steps; steps_last = t; }
 	void update(const double dt) { // dt_smooth = (dt+0.3)/(0.3/dt_smooth+1)
 		runtime_lbm_timestep_last = dt;

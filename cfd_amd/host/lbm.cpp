@@ -443,23 +443,26 @@ void LBM::voxelize_stl(const string& path, const float3x3& rotation, const float
 void LBM::voxelize_stl(const string& path, const float3& center, const float size, const uchar flag) { voxelize_stl(path, center, float3x3(1.0f), size, flag); }
 void LBM::voxelize_stl(const string& path, const float size, const uchar flag) { voxelize_stl(path, center(), float3x3(1.0f), size, flag); }
 
-void LBM::write_status(const string& path) { // lbm.cpp:1599-1643: key = value lines
+void LBM::write_status(const string& path) { // lbm.cpp:1599-1643: the same "key = value" lines
 	const string filename = default_filename(path, "status", ".txt", get_t());
 	create_folder(filename);
 	std::ofstream f(filename);
 	if (!f) { print_warning("Cannot write \""+filename+"\"."); return; }
-	f << "Grid Resolution = (" << Nx << ", " << Ny << ", " << Nz << ")\n";
-	f << "Grid Domains = (" << Dx << ", " << Dy << ", " << Dz << ")\n";
+	const double total = info.runtime_total();
+	f << "Grid Resolution = " << Nx << " x " << Ny << " x " << Nz << " = " << get_N() << "\n";
+	f << "Grid Domains = " << Dx << " x " << Dy << " x " << Dz << " = " << get_D() << "\n";
 	f << "LBM Type = D" << (velocity_set == 9u ? 2 : 3) << "Q" << velocity_set << " " << (collision == LBMHIP_TRT ? "TRT" : "SRT") << " (FP32/" << (storage == LBMHIP_FP32 ? "FP32" : storage == LBMHIP_FP16S ? "FP16S" : "FP16C") << ")\n";
 	f << "Memory Usage = CPU " << (uint)(get_N()*(ulong)bytes_per_cell_host()/1048576ull) << " MB, GPU " << get_D() << "x " << (uint)(lbm_domain[0]->get_N()*(ulong)bytes_per_cell_device()/1048576ull) << " MB\n";
-	f << "Maximum Allocation Size = " << (uint)(lbm_domain[0]->get_N()*(ulong)(velocity_set*(storage == LBMHIP_FP32 ? 4u : 2u))/1048576ull) << " MB\n";
-	f << "Time Steps = " << get_t() << " / " << (info.steps == max_ulong ? string("infinite") : to_string(info.steps_last+info.steps)) << "\n";
-	f << "Runtime = " << print_time(info.runtime_lbm) << " (total)\n";
+	f << "Maximum Allocation Size = " << (uint)(get_N()/(ulong)get_D()*(ulong)(velocity_set*(storage == LBMHIP_FP32 ? 4u : 2u))/1048576ull) << " MB\n";
+	f << "Time Steps = " << get_t() << " / " << (info.steps == max_ulong ? string("infinite") : to_string(info.steps)) << "\n";
+	f << "Runtime = " << print_time(total) << " (total) = " << print_time(info.runtime_lbm) << " (LBM) + " << print_time(std::max(total-info.runtime_lbm, 0.0)) << " (rendering and data evaluation)\n";
+	f << "Average MLUPs/s = " << (info.runtime_lbm > 0.0 ? to_uint(1E-6*(double)get_N()*(double)get_t()/info.runtime_lbm) : 0u) << "\n";
 	f << "Kinematic Viscosity = " << to_string(get_nu()) << "\n";
 	f << "Relaxation Time = " << to_string(get_tau()) << "\n";
 	f << "Maximum Reynolds Number = " << to_string(get_Re_max()) << "\n";
+#ifdef VOLUME_FORCE
 	f << "Volume Force = (" << to_string(get_fx()) << ", " << to_string(get_fy()) << ", " << to_string(get_fz()) << ")\n";
-	if (info.runtime_lbm > 0.0) f << "Average MLUPs/s = " << to_string((float)((double)get_N()*(double)get_t()/info.runtime_lbm*1E-6), 1u) << "\n"; // N*t/runtime (lbm.cpp:1623-1626)
+#endif
 	f.close();
 	print_info("File \""+filename+"\" saved.");
 }

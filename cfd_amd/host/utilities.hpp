@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <functional>
 #include <iostream>
@@ -102,8 +103,19 @@ inline string to_string(const uint x) { return std::to_string(x); }
 inline string to_string(const int x) { return std::to_string(x); }
 inline string to_string(const ulong x) { return std::to_string((unsigned long long)x); }
 inline string to_string(const slong x) { return std::to_string((long long)x); }
-inline string to_string(const float x) { char b[48]; std::snprintf(b, sizeof(b), "%.9g", (double)x); return string(b); } // 9 digits round-trip a float
-inline string to_string(const double x) { char b[64]; std::snprintf(b, sizeof(b), "%.17g", x); return string(b); }
+// d.dddd[E<exponent>] with the mantissa in [1,10) and the exponent left out when it is 0: the text format of the reference's
+// to_string(float) / to_string(double) (FluidX3D-master/src/utilities.hpp:2745-2765), which its VTK headers and status files carry
+inline string scientific(const double x, const int decimals) {
+	if (std::isnan(x)) return "NaN";
+	if (std::isinf(x)) return x < 0.0 ? "-Inf" : "Inf";
+	char b[64]; std::snprintf(b, sizeof(b), "%.*E", decimals, x);
+	char* e = std::strchr(b, 'E');
+	const int exponent = std::atoi(e+1);
+	*e = 0;
+	return string(b)+(exponent != 0 ? "E"+std::to_string(exponent) : "");
+}
+inline string to_string(const float x) { return scientific((double)x, 8); }
+inline string to_string(const double x) { return scientific(x, 16); }
 inline string to_string(const float x, const uint decimals) { char b[64]; std::snprintf(b, sizeof(b), "%.*f", (int)decimals, (double)x); return string(b); }
 inline string to_string(const double x, const uint decimals) { char b[64]; std::snprintf(b, sizeof(b), "%.*f", (int)decimals, x); return string(b); }
 inline uint length(const string& s) { return (uint)s.length(); }

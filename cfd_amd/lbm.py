@@ -209,6 +209,35 @@ class LBM:
     def bytes_per_cell_device(self):
         return self._L.lbmhip_bytes_per_cell_device(self.Q, STORAGE[self.storage], feature_mask(self.features))
 
+    # ---- Memory_Container::write_device_to_vtk (lbm.hpp:298-340): legacy VTK, binary, big-endian, STRUCTURED_POINTS,
+    # components interleaved per cell, file name <field>-<t as 9 digits>.vtk; lattice units (the SI factors of units.hpp are 1)
+    def write_device_to_vtk(self, name, path=""):
+        self.read_from_device()
+        return self.write_host_to_vtk(name, path)
+
+    def write_host_to_vtk(self, name, path=""):
+        a = getattr(self, name)
+        if a is None:
+            raise LbmHipError("field %s does not exist (FORCE_FIELD is off)" % name)
+        Nx, Ny, Nz = self.N
+        d = 3 if a.ndim == 4 else 1
+        if path == "" or path.endswith("/"):
+            path = (path or "./") + "%s-%09d.vtk" % (name, self.t)
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        kind = "unsigned_char" if a.dtype == np.uint8 else "float"
+        def f6(v):  # the reference's to_string(float): d.dddddddd[E<exponent>] (utilities.hpp:2745-2754)
+            m, e = ("%.8E" % v).split("E")
+            return m + ("E%d" % int(e) if int(e) else "")
+        header = ("# vtk DataFile Version 3.0\nFluidX3D %s\nBINARY\nDATASET STRUCTURED_POINTS\nDIMENSIONS %d %d %d\nORIGIN %s %s %s\n"
+                  "SPACING %s %s %s\nPOINT_DATA %d\nSCALARS data %s %d\nLOOKUP_TABLE default\n") % (
+            os.path.basename(path), Nx, Ny, Nz, f6(0.5 - 0.5 * Nx), f6(0.5 - 0.5 * Ny), f6(0.5 - 0.5 * Nz), f6(1.0), f6(1.0), f6(1.0), Nx * Ny * Nz, kind, d)
+        with open(path, "wb") as f:
+            f.write(header.encode())
+            for z in range(Nz):  # plane by plane: SoA -> interleaved, byte-swapped
+                plane = np.moveaxis(a[:, z], 0, -1) if d == 3 else a[z]
+                f.write(np.ascontiguousarray(plane).astype(">f4" if a.dtype == np.float32 else np.uint8).tobytes())
+        return path
+
     def get_tuning(self, key):
         """Launch setting of the first domain ("cells_per_thread", "blocks_per_cu", "block", "autotune", "tuned")."""
         v = C.c_int()

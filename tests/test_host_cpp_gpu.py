@@ -45,7 +45,8 @@ def test_taylor_green_example_matches_python_mirror(gpu):
     err = np.linalg.norm((np.moveaxis(data, 3, 0) - full).ravel().astype(np.float64)) / np.linalg.norm(full.ravel().astype(np.float64))
     assert err < 1e-4
     status = open(os.path.join(BIN, "export", "status-000000100.txt")).read()
-    assert "Grid Resolution = (128, 128, 128)" in status and "Average MLUPs/s" in status
+    assert "Grid Resolution = 128 x 128 x 128 = 2097152\n" in status and "LBM Type = D3Q19 SRT (FP32/FP32)\n" in status
+    assert re.search(r"Average MLUPs/s = \d+\n", status) and "Kinematic Viscosity = 9.99999978E-3\n" in status and "Volume Force" not in status
 
 
 def test_cavity_example_runs(gpu):
@@ -123,3 +124,24 @@ def test_benchmark_example_reports_peak_mlups(gpu, name, floor):
     out = run_example(name, env={"LBM_BENCH_BATCHES": "100"})
     mlups = int([l for l in out.splitlines() if l.startswith("peak_mlups ")][0].split()[1])
     assert mlups > floor, out
+
+
+def test_python_vtk_writer_matches_the_cpp_host_layout(gpu, tmp_path):
+    """The ctypes mirror writes the same legacy-VTK layout as the C++ host (header lines, big-endian interleaved payload)."""
+    with cfd_amd.LBM((24, 16, 8), 0.02, features=("FORCE_FIELD",)) as lbm:
+        setups.taylor_green(lbm)
+        lbm.flags[2, 3, 4] = 1
+        lbm.run(7)
+        paths = [lbm.write_device_to_vtk(n, str(tmp_path) + "/") for n in ("u", "rho", "flags", "F")]
+        assert os.path.basename(paths[0]) == "u-000000007.vtk"
+        for p, name, comps, dt in zip(paths, ("u", "rho", "flags", "F"), (3, 1, 1, 3), (">f4", ">f4", np.uint8, ">f4")):
+            raw = open(p, "rb").read()
+            end = raw.index(b"LOOKUP_TABLE default\n") + len(b"LOOKUP_TABLE default\n")
+            head = raw[:end].decode().splitlines()
+            assert head[0] == "# vtk DataFile Version 3.0" and head[2] == "BINARY" and head[3] == "DATASET STRUCTURED_POINTS"
+            assert head[4] == "DIMENSIONS 24 16 8" and head[5] == "ORIGIN -1.15000000E1 -7.50000000 -3.50000000" and head[6] == "SPACING 1.00000000 1.00000000 1.00000000"
+            assert head[7] == "POINT_DATA 3072" and head[8].startswith("SCALARS data ") and head[8].endswith(" %d" % comps)
+            data = np.frombuffer(raw[end:], dtype=dt)
+            want = getattr(lbm, name)
+            want = np.moveaxis(want, 0, -1) if comps == 3 else want
+            assert np.array_equal(data.reshape(want.shape), want)
