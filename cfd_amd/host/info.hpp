@@ -13,7 +13,9 @@ struct Info {
 	std::mutex allow_printing;
 	Clock since_start;                          // wall clock since the program started (runtime_total of the reference)
 	double runtime_total() { return since_start.stop(); }
-	void append(const ulong steps, const ulong total_steps, const ulong t) { (void)total_steps; this->steps = steps; steps_last = t; }
+	void append(const ulong steps, const ulong total_steps, const ulong t) { // info.cpp:6-15: total_steps, when given, is the length of the whole run
+		if (total_steps == max_ulong) { this->steps = steps; steps_last = t; } else this->steps = total_steps;
+	}
 	void update(const double dt) { // dt_smooth = (dt+0.3)/(0.3/dt_smooth+1)
 		runtime_lbm_timestep_last = dt;
 		runtime_lbm_timestep_smooth = (dt+0.3)/(0.3/runtime_lbm_timestep_smooth+1.0);

@@ -129,10 +129,24 @@ inline void print_warning(const string& s) { println("| Warning: "+s); }
 	std::cerr << "| Error: " << s << std::endl;
 	std::exit(1);
 }
+// "<y>y<ddd>d<hh>h<mm>m<ss>s": units above the first non-zero one are left out, units below it are zero-padded
+// (the text the reference prints, FluidX3D-master/src/utilities.hpp:2876-2888), e.g. "7s", "1m05s", "2h03m07s"
 inline string print_time(const double seconds) {
-	const ulong t = (ulong)std::max(seconds, 0.0);
-	char b[64]; std::snprintf(b, sizeof(b), "%llud %02lluh %02llum %02llus", (unsigned long long)(t/86400ull), (unsigned long long)(t%86400ull/3600ull), (unsigned long long)(t%3600ull/60ull), (unsigned long long)(t%60ull));
-	return string(b);
+	ulong rest = (ulong)(std::max(seconds, 0.0)+0.5);
+	const ulong unit[4] = {31556925ull, 86400ull, 3600ull, 60ull};
+	const char tag[4] = {'y', 'd', 'h', 'm'};
+	const int width[4] = {1, 3, 2, 2};
+	string out;
+	bool shown = false;
+	for (int k = 0; k < 4; k++) {
+		const ulong v = rest/unit[k];
+		rest %= unit[k];
+		if (!shown && v == 0ull) continue;
+		char b[32]; std::snprintf(b, sizeof(b), "%0*llu%c", shown ? width[k] : 1, (unsigned long long)v, tag[k]);
+		out += b; shown = true;
+	}
+	char b[32]; std::snprintf(b, sizeof(b), "%0*llus", shown ? 2 : 1, (unsigned long long)rest);
+	return out+b;
 }
 inline void sleep(const double seconds) { std::this_thread::sleep_for(std::chrono::microseconds((long long)(seconds*1E6))); }
 inline void wait() {}
