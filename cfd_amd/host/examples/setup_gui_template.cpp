@@ -25,6 +25,11 @@ void main_setup() {
 	lbm.graphics.visualization_modes = VIS_FLAG_LATTICE|VIS_FLAG_SURFACE|VIS_Q_CRITERION;
 	const string export_path = get_exe_path()+"export/";
 	lbm.write_status(export_path);
+	{ // the body as the reference would export it beside the fields
+		Mesh* mesh = read_stl(stl_env ? string(stl_env) : get_exe_path()+"../stl/body.stl", lbm.size(), center, rotation, size);
+		lbm.write_mesh_to_vtk(mesh, export_path);
+		delete mesh;
+	}
 	lbm.run(0u, lbm_T);
 	key_9 = true; // one export, as if the GUI had pressed the key
 	while (lbm.get_t() < lbm_T && running) {

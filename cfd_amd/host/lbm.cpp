@@ -443,6 +443,36 @@ void LBM::voxelize_stl(const string& path, const float3x3& rotation, const float
 void LBM::voxelize_stl(const string& path, const float3& center, const float size, const uchar flag) { voxelize_stl(path, center, float3x3(1.0f), size, flag); }
 void LBM::voxelize_stl(const string& path, const float size, const uchar flag) { voxelize_stl(path, center(), float3x3(1.0f), size, flag); }
 
+// Triangle soup as legacy VTK POLYDATA, binary big-endian, positions relative to the box centre (lbm.cpp:1682-1724)
+void LBM::write_mesh_to_vtk(const Mesh* mesh, const string& path, const bool convert_to_si_units) const {
+	const string filename = default_filename(path, "mesh", ".vtk", get_t());
+	const uint T = mesh->triangle_number;
+	const float spacing = convert_to_si_units ? units.si_x(1.0f) : 1.0f;
+	const float3 offset = center();
+	vector<float> points(9ull*T);
+	vector<int> polygons(4ull*T);
+	parallel_for((ulong)T, [&](ulong i) {
+		const float3 v[3] = {mesh->p0[i], mesh->p1[i], mesh->p2[i]};
+		for (uint k = 0u; k < 3u; k++) {
+			points[9ull*i+3ull*k] = reverse_bytes(spacing*(v[k].x-offset.x));
+			points[9ull*i+3ull*k+1ull] = reverse_bytes(spacing*(v[k].y-offset.y));
+			points[9ull*i+3ull*k+2ull] = reverse_bytes(spacing*(v[k].z-offset.z));
+			polygons[4ull*i+1ull+k] = reverse_bytes((int)(3ull*i+k));
+		}
+		polygons[4ull*i] = reverse_bytes(3);
+	});
+	create_folder(filename);
+	std::ofstream file(filename, std::ios::out|std::ios::binary);
+	if (!file) print_error("Cannot write file \""+filename+"\".");
+	const string head = "# vtk DataFile Version 3.0\nFluidX3D "+filename.substr(filename.rfind('/')+1)+"\nBINARY\nDATASET POLYDATA\nPOINTS "+to_string(3u*T)+" float\n";
+	const string mid = "POLYGONS "+to_string(T)+" "+to_string(4u*T)+"\n";
+	file.write(head.c_str(), (std::streamsize)head.length());
+	file.write((const char*)points.data(), (std::streamsize)(points.size()*sizeof(float)));
+	file.write(mid.c_str(), (std::streamsize)mid.length());
+	file.write((const char*)polygons.data(), (std::streamsize)(polygons.size()*sizeof(int)));
+	file.close();
+	print_info("File \""+filename+"\" saved.");
+}
 void LBM::write_status(const string& path) { // lbm.cpp:1599-1643: the same "key = value" lines
 	const string filename = default_filename(path, "status", ".txt", get_t());
 	create_folder(filename);

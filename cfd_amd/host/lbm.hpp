@@ -205,6 +205,18 @@ public:
 	uint largest_side_length() const { return max(max(Nx, Ny), Nz); }
 	float3 relative_position(const uint x, const uint y, const uint z) const { return float3(((float)x+0.5f)/(float)Nx-0.5f, ((float)y+0.5f)/(float)Ny-0.5f, ((float)z+0.5f)/(float)Nz-0.5f); }
 	float3 relative_position(const ulong n) const { uint x, y, z; coordinates(n, x, y, z); return relative_position(x, y, z); }
+	float3 mirror_position(const float3& p) const { // wraps a position into the periodic box (lbm.hpp:509-515)
+		auto wrap = [](const float v, const float n) { return sign(v)*(std::fmod(std::fabs(v)+0.5f*n, n)-0.5f*n); };
+		return float3(wrap(p.x, (float)Nx), wrap(p.y, (float)Ny), wrap(p.z, (float)Nz));
+	}
+	void coordinates(const float3& p, uint& x, uint& y, uint& z) const { // closest lattice point (lbm.hpp:484-489)
+		const float3 mp = mirror_position(p);
+		x = (uint)(mp.x+1.5f*(float)Nx)%Nx; y = (uint)(mp.y+1.5f*(float)Ny)%Ny; z = (uint)(mp.z+1.5f*(float)Nz)%Nz;
+	}
+	float get_sigma() const { return 0.0f; } // SURFACE and TEMPERATURE are not provided
+	float get_alpha() const { return 0.0f; }
+	float get_beta() const { return 0.0f; }
+	void write_mesh_to_vtk(const Mesh* mesh, const string& path = "", const bool convert_to_si_units = true) const; // lbm.cpp:1682-1724
 	void write_status(const string& path = ""); // lbm.cpp:1599-1643
 
 	void voxelize_mesh_on_device(const Mesh* mesh, const uchar flag = TYPE_S, const float3& rotation_center = float3(0.0f), const float3& linear_velocity = float3(0.0f), const float3& rotational_velocity = float3(0.0f)); // lbm.cpp:1645-1670

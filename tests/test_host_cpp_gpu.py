@@ -76,6 +76,13 @@ def test_gui_template_example(gpu, tmp_path):
         head = raw[:raw.index(b"LOOKUP_TABLE default\n")].decode()
         assert "SCALARS data %s %d" % (kind, comps) in head and "DIMENSIONS %d %d %d" % (nx, ny, nz) in head
     assert os.path.exists(os.path.join(BIN, "export", "status-000000060.txt"))
+    raw = open(os.path.join(BIN, "export", "mesh-000000000.vtk"), "rb").read()   # POLYDATA: 1024 triangles of the torus
+    assert raw.startswith(b"# vtk DataFile Version 3.0\nFluidX3D mesh-000000000.vtk\nBINARY\nDATASET POLYDATA\nPOINTS 3072 float\n")
+    k = raw.index(b"POLYGONS 1024 4096\n")
+    pts = np.frombuffer(raw[raw.index(b"float\n") + 6:k], dtype=">f4").reshape(-1, 3)
+    assert pts.shape == (3072, 3) and np.abs(pts).max() < 0.5 * nx and abs(float(np.ptp(pts, axis=0).max()) - 0.5 * nz) < 0.05
+    tri = np.frombuffer(raw[k + len(b"POLYGONS 1024 4096\n"):], dtype=">i4").reshape(-1, 4)
+    assert (tri[:, 0] == 3).all() and np.array_equal(tri[:, 1:].ravel(), np.arange(3072))
 
 
 def test_fluid_wrapper_as_solver_py_binds_it(gpu, tmp_path):
