@@ -88,7 +88,7 @@ string default_filename(const string& name, const string& extension, const ulong
 
 static void check(const int status) { if (status) print_error(lbmhip_last_error()); }
 
-Mesh* read_stl(const string& path, const float3& box_size, const float3& center, const float3x3& rotation, const float size) {
+Mesh* read_stl_raw(const string& path, const bool reposition, const float3& box_size, const float3& center, const float3x3& rotation, const float size) {
 	const string filename = create_file_extension(path, ".stl");
 	std::ifstream file(filename, std::ios::in|std::ios::binary);
 	if (file.fail()) print_error("File \""+filename+"\" does not exist!");
@@ -108,7 +108,7 @@ Mesh* read_stl(const string& path, const float3& box_size, const float3& center,
 	}
 	mesh->find_bounds();
 	const float scale = size == 0.0f ? mesh->get_scale_for_box_fit(box_size) : size > 0.0f ? size/mesh->get_max_size() : -size;
-	const float3 offset = -0.5f*(mesh->pmin+mesh->pmax);
+	const float3 offset = reposition ? -0.5f*(mesh->pmin+mesh->pmax) : float3(0.0f);
 	for (uint i = 0u; i < triangle_number; i++) {
 		mesh->p0[i] = center+scale*(offset+mesh->p0[i]);
 		mesh->p1[i] = center+scale*(offset+mesh->p1[i]);
@@ -213,6 +213,7 @@ LBM::LBM(const uint3 N, const float nu, const float fx, const float fy, const fl
 
 LBM::LBM(const uint Nx, const uint Ny, const uint Nz, const uint Dx, const uint Dy, const uint Dz, const float nu, const float fx, const float fy, const float fz, const float sigma, const float alpha, const float beta, const uint particles_N, const float particles_rho) {
 	(void)particles_rho;
+	graphics.lbm = this;
 	if (Dx*Dy*Dz == 0u) print_error("You specified 0 LBM grid domains ("+to_string(Dx)+"x"+to_string(Dy)+"x"+to_string(Dz)+"). There has to be at least 1 domain in every direction. Check your input in LBM constructor.");
 	const uint NDx = (Nx/Dx)*Dx, NDy = (Ny/Dy)*Dy, NDz = (Nz/Dz)*Dz; // make the resolution divisible by the domains (lbm.cpp:1043-1054)
 	if (NDx != Nx || NDy != Ny || NDz != Nz) print_warning("LBM grid ("+to_string(Nx)+"x"+to_string(Ny)+"x"+to_string(Nz)+") is not equally divisible in domains ("+to_string(Dx)+"x"+to_string(Dy)+"x"+to_string(Dz)+"). Changing resolution to ("+to_string(NDx)+"x"+to_string(NDy)+"x"+to_string(NDz)+").");

@@ -9,6 +9,7 @@
 #include "units.hpp"
 #include "info.hpp"
 #include "graphics.hpp"
+#include "shapes.hpp"
 #include "../../include/lbmhip.h"
 
 uint bytes_per_cell_host();                 // FluidX3D-master/src/lbm.cpp:23-36
@@ -146,7 +147,27 @@ public:
 	Memory_Container<float> F;
 #endif
 
-	struct Graphics { int visualization_modes = 0, field_mode = 0, slice_mode = 0, slice_x = 0, slice_y = 0, slice_z = 0; } graphics; // accepted, not rendered
+	// There is no renderer: camera and frame calls of a setup are accepted and do nothing, so that setups written for the
+	// reference's GRAPHICS mode (lbm.hpp:560-611) compile and run headless; next_frame keeps its pacing (lbm.cpp:1900-1914).
+	struct Graphics {
+		LBM* lbm = nullptr;
+		int visualization_modes = 0, field_mode = 0, slice_mode = 0, slice_x = 0, slice_y = 0, slice_z = 0;
+		uint last_exported_frame = max_uint;
+		void set_camera_centered(const float rx = 0.0f, const float ry = 0.0f, const float fov = 100.0f, const float zoom = 1.0f) {}
+		void set_camera_free(const float3& p = float3(0.0f), const float rx = 0.0f, const float ry = 0.0f, const float fov = 100.0f) {}
+		bool next_frame(const ulong total_time_steps, const float video_length_seconds) { // true once per frame of a 60 fps video of that length
+			const uint frame = to_uint((float)lbm->get_t()/(float)total_time_steps*video_length_seconds*60.0f);
+			if (frame == last_exported_frame) return false;
+			last_exported_frame = frame;
+			return true;
+		}
+		void print_frame() {}
+		void write_frame(const string& path = "", const string& name = "image", const string& extension = ".png", bool print_preview = false) {}
+		void write_frame(const uint x1, const uint y1, const uint x2, const uint y2, const string& path = "", const string& name = "image", const string& extension = ".png", bool print_preview = false) {}
+		void write_frame_png(const string& path = "", bool print_preview = false) {}
+		void write_frame_qoi(const string& path = "", bool print_preview = false) {}
+		void write_frame_bmp(const string& path = "", bool print_preview = false) {}
+	} graphics;
 
 	LBM(const uint Nx, const uint Ny, const uint Nz, const uint Dx, const uint Dy, const uint Dz, const float nu, const float fx = 0.0f, const float fy = 0.0f, const float fz = 0.0f, const float sigma = 0.0f, const float alpha = 0.0f, const float beta = 0.0f, const uint particles_N = 0u, const float particles_rho = 0.0f);
 	LBM(const uint Nx, const uint Ny, const uint Nz, const float nu, const float fx = 0.0f, const float fy = 0.0f, const float fz = 0.0f, const float sigma = 0.0f, const float alpha = 0.0f, const float beta = 0.0f, const uint particles_N = 0u, const float particles_rho = 1.0f);

@@ -43,6 +43,14 @@ inline float rsqrt(const float x) { return 1.0f/std::sqrt(x); }
 inline uint to_uint(const float x) { return (uint)std::fmax(std::fmin(x+0.5f, 4294967040.0f), 0.0f); }
 inline uint to_uint(const double x) { return (uint)std::fmax(std::fmin(x+0.5, 4294967295.0), 0.0); }
 inline ulong to_ulong(const float x) { return (ulong)std::fmax(x+0.5f, 0.0f); }
+// a sampled series has settled when both its last difference and its last second difference are below `threshold` times
+// the mean of the last three samples (the stop criterion of the reference's validation setups, utilities.hpp:208-213)
+template <class T> inline bool converged_impl(const T a, const T b, const T c, const T threshold) {
+	const T bound = (a+b+c)/(T)3*threshold;
+	return std::fabs(c-b) < bound && std::fabs(c-(T)2*b+a) < bound;
+}
+inline bool converged(const float x_penultimate, const float x_last, const float x, const float threshold = 1E-5f) { return converged_impl<float>(x_penultimate, x_last, x, threshold); }
+inline bool converged(const double x_penultimate, const double x_last, const double x, const double threshold = 1E-5) { return converged_impl<double>(x_penultimate, x_last, x, threshold); }
 inline uint gcd(uint a, uint b) { while (b) { const uint t = a%b; a = b; b = t; } return a; }
 inline uint lcm(const uint a, const uint b) { return a/gcd(a, b)*b; }
 
@@ -63,6 +71,8 @@ struct float3 {
 	float3& operator+=(const float3& b) { x += b.x; y += b.y; z += b.z; return *this; }
 	float3& operator-=(const float3& b) { x -= b.x; y -= b.y; z -= b.z; return *this; }
 	float3& operator*=(const float s) { x *= s; y *= s; z *= s; return *this; }
+	float3& operator/=(const float s) { x /= s; y /= s; z /= s; return *this; }
+	float3(const uint3& v) : x((float)v.x), y((float)v.y), z((float)v.z) {}
 };
 inline float3 operator+(const float3& a, const float3& b) { return float3(a.x+b.x, a.y+b.y, a.z+b.z); }
 inline float3 operator-(const float3& a, const float3& b) { return float3(a.x-b.x, a.y-b.y, a.z-b.z); }
@@ -198,13 +208,42 @@ struct Mesh {
 			pmax = float3(std::fmax(p.x, pmax.x), std::fmax(p.y, pmax.y), std::fmax(p.z, pmax.z));
 		}
 	}
+	// rigid and similarity transforms about `center` (utilities.hpp:4470-4496); the bounds follow the mesh
+	void scale(const float factor) {
+		for (uint i = 0u; i < triangle_number; i++) { p0[i] = factor*(p0[i]-center)+center; p1[i] = factor*(p1[i]-center)+center; p2[i] = factor*(p2[i]-center)+center; }
+		pmin = factor*(pmin-center)+center; pmax = factor*(pmax-center)+center;
+	}
+	void translate(const float3& shift) {
+		for (uint i = 0u; i < triangle_number; i++) { p0[i] += shift; p1[i] += shift; p2[i] += shift; }
+		center += shift; pmin += shift; pmax += shift;
+	}
+	void rotate(const float3x3& rotation) {
+		for (uint i = 0u; i < triangle_number; i++) { p0[i] = rotation*(p0[i]-center)+center; p1[i] = rotation*(p1[i]-center)+center; p2[i] = rotation*(p2[i]-center)+center; }
+		find_bounds();
+	}
+	void set_center(const float3& c) { center = c; }
+	const float3& get_center() const { return center; }
+	float3 get_center_of_mass() const { // centroid of the enclosed volume: signed tetrahedra between the origin and every triangle
+		double V = 0.0, cx = 0.0, cy = 0.0, cz = 0.0;
+		for (uint i = 0u; i < triangle_number; i++) {
+			const double dV = (double)dot(p0[i], cross(p1[i], p2[i]))/6.0;
+			const float3 quarter = 0.25f*(p0[i]+p1[i]+p2[i]);
+			V += dV; cx += dV*(double)quarter.x; cy += dV*(double)quarter.y; cz += dV*(double)quarter.z;
+		}
+		return float3((float)(cx/V), (float)(cy/V), (float)(cz/V));
+	}
+	float get_min_size() const { return std::fmin(std::fmin(pmax.x-pmin.x, pmax.y-pmin.y), pmax.z-pmin.z); }
 	float get_max_size() const { return std::fmax(std::fmax(pmax.x-pmin.x, pmax.y-pmin.y), pmax.z-pmin.z); }
 	float get_scale_for_box_fit(const float3& box) const { return std::fmin(std::fmin(box.x/(pmax.x-pmin.x), box.y/(pmax.y-pmin.y)), box.z/(pmax.z-pmin.z)); }
 	float3 get_bounding_box_size() const { return pmax-pmin; }
 	float3 get_bounding_box_center() const { return 0.5f*(pmin+pmax); }
 };
-// rotate, rescale (size 0: largest that fits the box; >0: longest side = size; <0: factor -size) and re-centre on `center`
-Mesh* read_stl(const string& path, const float3& box_size, const float3& center, const float3x3& rotation, const float size); // defined in lbm.cpp
+// rotate, rescale (size 0: largest that fits the box; >0: longest side = size; <0: factor -size) and, with `reposition`,
+// move the bounding-box centre to `center` (otherwise `center` is an offset); utilities.hpp:4530-4581
+Mesh* read_stl_raw(const string& path, const bool reposition, const float3& box_size, const float3& center, const float3x3& rotation, const float size); // defined in lbm.cpp
+inline Mesh* read_stl(const string& path, const float3& box_size, const float3& center, const float3x3& rotation, const float size) { return read_stl_raw(path, true, box_size, center, rotation, size); }
+inline Mesh* read_stl(const string& path, const float3& box_size, const float3& center, const float size) { return read_stl_raw(path, true, box_size, center, float3x3(1.0f), size); }
+inline Mesh* read_stl(const string& path, const float scale = 1.0f, const float3x3& rotation = float3x3(1.0f), const float3& offset = float3(0.0f)) { return read_stl_raw(path, false, float3(1.0f), offset, rotation, -std::fabs(scale)); }
 
 template <class T> inline T reverse_bytes(const T value) {
 	T r; const char* a = (const char*)&value; char* b = (char*)&r;
