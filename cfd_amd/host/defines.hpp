@@ -25,8 +25,6 @@
 #define UPDATE_FIELDS
 #endif
 
-#define WORKGROUP_SIZE 64 // some setups size their box in multiples of it (FluidX3D-master/src/opencl.hpp:3)
-
 // cell flags (FluidX3D-master/src/defines.hpp:25-32)
 #define TYPE_S 0x01 // solid boundary (stationary or moving)
 #define TYPE_E 0x02 // equilibrium boundary (inflow/outflow)

@@ -26,6 +26,9 @@ typedef unsigned int uint;
 typedef uint64_t ulong;
 typedef int64_t slong;
 
+#ifndef WORKGROUP_SIZE
+#define WORKGROUP_SIZE 64 // some setups size their box in multiples of it (FluidX3D-master/src/opencl.hpp:3)
+#endif
 constexpr float pif = 3.1415927f;
 constexpr double pi = 3.141592653589793;
 constexpr uint max_uint = std::numeric_limits<uint>::max();

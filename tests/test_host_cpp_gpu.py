@@ -152,3 +152,51 @@ def test_python_vtk_writer_matches_the_cpp_host_layout(gpu, tmp_path):
             want = getattr(lbm, name)
             want = np.moveaxis(want, 0, -1) if comps == 3 else want
             assert np.array_equal(data.reshape(want.shape), want)
+
+
+def test_keys_reach_a_running_setup_through_stdin_and_signals(gpu, tmp_path):
+    """The GUI drives the reference through its window (run/pause 'P', export '9', quit); here the same keys arrive on
+    standard input or as signals and show up in the setup's loop through running / key_P / key_9."""
+    import glob
+    import signal
+    import time
+    from cfd_amd import mesh as M
+    stl = str(tmp_path / "body.stl")
+    M.write_stl(stl, *M.torus())
+    exe = os.path.join(BIN, "gui_template")
+    export = os.path.join(BIN, "export")
+    for f in glob.glob(os.path.join(export, "u-*.vtk")):
+        os.remove(f)
+    p = subprocess.Popen([exe], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                         env=dict(os.environ, LBM_EXAMPLE_STL=stl, LBM_EXAMPLE_STEPS="100000000"))
+    try:
+        def exports():
+            return sorted(glob.glob(os.path.join(export, "u-*.vtk")))
+        deadline = time.time() + 60
+        while not exports() and time.time() < deadline:   # the example exports once at t = 0 by itself
+            time.sleep(0.05)
+        assert len(exports()) == 1
+        p.stdin.write(b"9"); p.stdin.flush()               # export trigger through stdin
+        while len(exports()) < 2 and time.time() < deadline:
+            time.sleep(0.05)
+        assert len(exports()) == 2
+        p.send_signal(signal.SIGUSR2)                      # pause
+        time.sleep(0.3)
+        p.send_signal(signal.SIGUSR1)                      # export while paused: the loop still serves key_9
+        while len(exports()) < 3 and time.time() < deadline:
+            time.sleep(0.05)
+        assert len(exports()) == 3
+        t_paused = int(re.search(r"u-(\d+)\.vtk", exports()[-1]).group(1))
+        time.sleep(0.3)
+        stamp = os.stat(exports()[-1]).st_mtime_ns
+        p.stdin.write(b"9"); p.stdin.flush()               # a second export while paused lands on the same time step: same file, rewritten
+        while os.stat(exports()[-1]).st_mtime_ns == stamp and time.time() < deadline:
+            time.sleep(0.05)
+        assert len(exports()) == 3 and os.stat(exports()[-1]).st_mtime_ns != stamp
+        assert int(re.search(r"u-(\d+)\.vtk", exports()[-1]).group(1)) == t_paused     # no step was taken while paused
+        p.stdin.write(b"PQ"); p.stdin.flush()              # resume, then quit
+        out, _ = p.communicate(timeout=60)
+        assert p.returncode == 0 and "grid " in out.decode()
+    finally:
+        if p.poll() is None:
+            p.kill()
