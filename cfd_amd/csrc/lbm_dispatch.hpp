@@ -7,9 +7,9 @@ namespace lbm {
 
 typedef hipError_t (*collide_launch_fn)(const Args&, dim3 grid, dim3 block, uint32_t lds_bytes, hipStream_t stream);
 
-template <int Q, int ST, int COLL, int FEAT, int V, bool FO>
+template <int Q, int ST, int COLL, int FEAT, bool FO>
 hipError_t launch_collide(const Args& a, dim3 grid, dim3 block, uint32_t lds_bytes, hipStream_t stream) {
-	hipLaunchKernelGGL((k_collide<Q, ST, COLL, FEAT, V, FO>), grid, block, lds_bytes, stream, a);
+	hipLaunchKernelGGL((k_collide<Q, ST, COLL, FEAT, FO>), grid, block, lds_bytes, stream, a);
 	return hipGetLastError();
 }
 
@@ -23,8 +23,8 @@ hipError_t launch_collide_wide(const Args& a, dim3 grid, dim3 block, uint32_t ld
 template <int Q, int ST, int COLL, int FEAT> collide_launch_fn pick_v(int V) {
 	switch (V) {
 		case 4: return launch_collide_wide<Q, ST, COLL, FEAT, 4>;
-		case 2: if constexpr (ST == ST_FP32) return launch_collide_wide<Q, ST, COLL, FEAT, 2>; else return launch_collide<Q, ST, COLL, FEAT, 2, false>;
-		default: return launch_collide<Q, ST, COLL, FEAT, 1, false>;
+		case 2: return launch_collide_wide<Q, ST, COLL, FEAT, 2>;
+		default: return launch_collide<Q, ST, COLL, FEAT, false>;
 	}
 }
 
@@ -41,7 +41,7 @@ collide_launch_fn select_collide_small(int Q, int ST, int COLL, int FEAT, int V,
 #define LBM_SPECIALISE(Q, ST, MASK) \
 	if (FEAT == (MASK)) return COLL == COLL_TRT ? pick_v<Q, ST, COLL_TRT, (MASK)>(V) : pick_v<Q, ST, COLL_SRT, (MASK)>(V);
 #define LBM_GENERIC(Q, ST) \
-	if (FO) return COLL == COLL_TRT ? launch_collide<Q, ST, COLL_TRT, -1, 1, true> : launch_collide<Q, ST, COLL_SRT, -1, 1, true>; \
+	if (FO) return COLL == COLL_TRT ? launch_collide<Q, ST, COLL_TRT, -1, true> : launch_collide<Q, ST, COLL_SRT, -1, true>; \
 	if (FEAT < 0) return COLL == COLL_TRT ? pick_v<Q, ST, COLL_TRT, -1>(V) : pick_v<Q, ST, COLL_SRT, -1>(V);
 
 } // namespace lbm

@@ -1,190 +1,87 @@
-// lbm_kernels.hpp - the lattice kernels (templates) and their launchers.
+// lbm_kernels.hpp - the lattice kernels (templates).
 //
-// Thread mapping of the fused stream+collide kernel: one workgroup works on one lattice row (fixed y,z),
+// Thread mapping of the fused stream+collide kernels: one workgroup works on one lattice row (fixed y,z),
 // or on an x-chunk of it; y, z and every neighbour-row base are therefore wave-uniform (SGPRs) and only
-// the x offset is per lane.  Each lane handles V consecutive cells so that the x-aligned DDF slots move as
-// 4*V (FP32) or 2*V (FP16) byte accesses.  Every DDF slot is read and written by exactly one cell per
-// step (esoteric-pull, FluidX3D-master/src/kernel.cpp:1332-1345), so there is no inter-thread hazard and
-// the traffic is the algorithmic 2*Q*sizeof(fpxx) bytes per cell.
+// the x offset is per lane.  k_collide gives every lane one cell (4- or 2-byte accesses); k_collide_wide
+// gives it 2 or 4 consecutive cells moved as aligned vectors.  Every DDF slot is read and written by exactly
+// one cell per step (esoteric-pull, FluidX3D-master/src/kernel.cpp:1332-1345), so there is no inter-thread
+// hazard and the traffic is the algorithmic 2*Q*sizeof(fpxx) bytes per cell.
 #pragma once
 #include "lbm_device.hpp"
 
 namespace lbm {
 
-template <class T, int V> struct VecOf { typedef T type __attribute__((ext_vector_type(V))); };
-template <class T> struct VecOf<T, 1> { typedef T type; };
-
-// V consecutive raw DDFs starting at p[x]; ALIGNED says x*sizeof(raw) is a multiple of the vector size
-template <class raw, int V, bool ALIGNED> __device__ __forceinline__ void load_raw(const raw* __restrict__ p, uint32_t x, raw* out) {
-	if constexpr (V == 1) out[0] = p[x];
-	else if constexpr (ALIGNED) {
-		typedef typename VecOf<raw, V>::type vec;
-		const vec t = *reinterpret_cast<const vec*>(p+x);
-		for (int v = 0; v < V; v++) out[v] = t[v];
-	} else {
-		typedef typename VecOf<raw, V>::type vec;
-		vec t; __builtin_memcpy(&t, p+x, sizeof(vec));
-		for (int v = 0; v < V; v++) out[v] = t[v];
-	}
-}
-template <class raw, int V, bool ALIGNED> __device__ __forceinline__ void store_raw(raw* __restrict__ p, uint32_t x, const raw* in) {
-	if constexpr (V == 1) p[x] = in[0];
-	else {
-		typedef typename VecOf<raw, V>::type vec;
-		vec t;
-		for (int v = 0; v < V; v++) t[v] = in[v];
-		if constexpr (ALIGNED) *reinterpret_cast<vec*>(p+x) = t; else __builtin_memcpy(p+x, &t, sizeof(vec));
-	}
+// wall velocity terms of a cell next to moving solids (kernel.cpp:1111-1118): every pair looks at both neighbours
+template <int Q> __device__ __forceinline__ void apply_moving_boundaries(float* f, const Args& a, const uint32_t x, const uint32_t* yq, const uint32_t* zq) {
+	const uint32_t xq[3] = {x, x+1u == a.Nx ? 0u : x+1u, x == 0u ? a.Nx-1u : x-1u}; // index 0: same, 1: +1, 2: -1
+	static_for<1, Q, 2>([&](auto I) {
+		constexpr int i = I;
+		constexpr float w6 = -6.0f*weight<Q>(i);
+		auto nb = [&](auto J) -> uint64_t {
+			constexpr int jx = dir<Q>(J,0), jy = dir<Q>(J,1), jz = dir<Q>(J,2);
+			return ((uint64_t)zq[jz == 0 ? 0 : jz > 0 ? 1 : 2]*a.Ny+yq[jy == 0 ? 0 : jy > 0 ? 1 : 2])*a.Nx+xq[jx == 0 ? 0 : jx > 0 ? 1 : 2];
+		};
+		uint64_t ji = nb(std::integral_constant<int, i+1>{});
+		if ((a.flags[ji]&TYPE_BO) == TYPE_S) f[i] = fmaf(w6, cdot<Q, i+1>(a.u[ji], a.u[a.N+ji], a.u[2ull*a.N+ji]), f[i]);
+		ji = nb(std::integral_constant<int, i>{});
+		if ((a.flags[ji]&TYPE_BO) == TYPE_S) f[i+1] = fmaf(w6, cdot<Q, i>(a.u[ji], a.u[a.N+ji], a.u[2ull*a.N+ji]), f[i+1]);
+	});
 }
 
-// ---------------------------------------------------------------------------------------------- stream_collide / update_fields
+// ---------------------------------------------------------------------------------------------- stream_collide / update_fields, one cell per lane
 // FluidX3D-master/src/kernel.cpp:1470-1654 (FIELDS_ONLY=false) and 1812-1894 (FIELDS_ONLY=true).
 // FEAT >= 0: features fixed at compile time; FEAT < 0: taken from Args::features.
-template <int Q, int ST, int COLL, int FEAT, int V, bool FIELDS_ONLY>
+template <int Q, int ST, int COLL, int FEAT, bool FIELDS_ONLY>
 __global__ __launch_bounds__(256) void k_collide(const Args a) {
 	using S = Store<ST>;
 	using raw = typename S::raw;
 	// grid = (xchunks*Ny, planes): a launch may not exceed 2^32 work-items per grid dimension, and 1600^3 lattices do
 	const uint32_t chunk = blockIdx.x%a.xchunks, y = blockIdx.x/a.xchunks, z = a.z0+blockIdx.y;
 	if (a.hy && (y == 0u || y == a.Ny-1u)) return;
-	const uint32_t x = (chunk*blockDim.x+threadIdx.x)*V;
+	const uint32_t x = chunk*blockDim.x+threadIdx.x;
 	if (x >= a.Nx) return;
 
 	// wave-uniform row bases of the 3x3 neighbourhood in (y,z), periodic on the local lattice (kernel.cpp:914-925)
 	const uint32_t yq[3] = {y, y+1u == a.Ny ? 0u : y+1u, y == 0u ? a.Ny-1u : y-1u}; // index 0: same, 1: +1, 2: -1
 	const uint32_t zq[3] = {z, z+1u == a.Nz ? 0u : z+1u, z == 0u ? a.Nz-1u : z-1u};
-	const uint64_t row0 = ((uint64_t)z*a.Ny+y)*a.Nx;
+	const uint64_t row0 = ((uint64_t)z*a.Ny+y)*a.Nx, n = row0+x;
 	raw* const fi = static_cast<raw*>(a.fi);
 
-	// which of the V cells take part (solid cells and halo cells are skipped, kernel.cpp:1482-1485)
-	uint8_t flagsn[V];
-	bool active[V];
-	bool any = false;
-	if constexpr (V == 1) flagsn[0] = a.flags[row0+x];
-	else load_raw<uint8_t, V, true>(a.flags+row0, x, flagsn);
-#pragma unroll
-	for (int v = 0; v < V; v++) {
-		const uint32_t xv = x+(uint32_t)v;
-		active[v] = (flagsn[v]&TYPE_BO) != TYPE_S && !(a.hx && (xv == 0u || xv == a.Nx-1u));
-		any = any || active[v];
-	}
-	if (!any) return;
-
+	// solid cells and halo cells are skipped (kernel.cpp:1482-1485)
+	const uint8_t flagsn = a.flags[n], bo = flagsn&TYPE_BO;
+	if (bo == TYPE_S || (a.hx && (x == 0u || x == a.Nx-1u))) return;
 	auto feat = [&]() { if constexpr (FEAT >= 0) return StaticFeat<(uint32_t)(FEAT >= 0 ? FEAT : 0)>{}; else return DynamicFeat{a.features}; }();
 
-	// ---- streaming part 2: gather the DDFs of the V cells (kernel.cpp:1332-1338)
-	float f[V][Q];
-	{
-		raw t[V];
-		load_raw<raw, V, true>(fi+row0, x, t);
-#pragma unroll
-		for (int v = 0; v < V; v++) f[v][0] = S::decode(t[v]);
-	}
+	// ---- streaming part 2: gather (kernel.cpp:1332-1338); the +x / -x neighbour column, periodic
+	const uint32_t xp = x+1u == a.Nx ? 0u : x+1u, xm = x == 0u ? a.Nx-1u : x-1u;
+	float f[Q];
+	f[0] = S::decode(fi[n]);
 	static_for<1, Q, 2>([&](auto I) {
 		constexpr int i = I, cx = dir<Q>(i,0), cy = dir<Q>(i,1), cz = dir<Q>(i,2);
 		const uint32_t sA = a.odd ? i : i+1, sB = a.odd ? i+1 : i;
-		raw t[V];
-		load_raw<raw, V, true>(fi+(uint64_t)sA*a.N+row0, x, t);
-#pragma unroll
-		for (int v = 0; v < V; v++) f[v][i] = S::decode(t[v]);
+		f[i] = S::decode(fi[(uint64_t)sA*a.N+n]);
 		const raw* pn = fi+(uint64_t)sB*a.N+((uint64_t)zq[cz == 0 ? 0 : cz > 0 ? 1 : 2]*a.Ny+yq[cy == 0 ? 0 : cy > 0 ? 1 : 2])*a.Nx;
-		if constexpr (cx == 0) load_raw<raw, V, true>(pn, x, t);
-		else if constexpr (cx > 0) {
-			if (x+(uint32_t)V < a.Nx) load_raw<raw, V, false>(pn, x+1u, t);
-			else {
-#pragma unroll
-				for (int v = 0; v < V; v++) { const uint32_t xn = x+(uint32_t)v+1u; t[v] = pn[xn == a.Nx ? 0u : xn]; }
-			}
-		} else {
-			if (x > 0u) load_raw<raw, V, false>(pn, x-1u, t);
-			else {
-#pragma unroll
-				for (int v = 0; v < V; v++) { const uint32_t xv = x+(uint32_t)v; t[v] = pn[xv == 0u ? a.Nx-1u : xv-1u]; }
-			}
-		}
-#pragma unroll
-		for (int v = 0; v < V; v++) f[v][i+1] = S::decode(t[v]);
+		f[i+1] = S::decode(pn[cx == 0 ? x : cx > 0 ? xp : xm]);
 	});
 
-	// ---- per cell: boundaries, moments, collision
-	float rhon[V], uxn[V], uyn[V], uzn[V];
-	bool wf[V];
-#pragma unroll
-	for (int v = 0; v < V; v++) {
-		const uint32_t xv = x+(uint32_t)v;
-		const uint64_t n = row0+xv;
-		const uint8_t bo = flagsn[v]&TYPE_BO;
-		wf[v] = false;
-		if (!active[v]) continue;
-		if (feat(F_MOVING_BOUNDARIES) && bo == TYPE_MS) { // kernel.cpp:1111-1118
-			const uint32_t xq[3] = {xv, xv+1u == a.Nx ? 0u : xv+1u, xv == 0u ? a.Nx-1u : xv-1u};
-			static_for<1, Q, 2>([&](auto I) {
-				constexpr int i = I;
-				constexpr float w6 = -6.0f*weight<Q>(i);
-				auto nb = [&](auto J) -> uint64_t {
-					constexpr int jx = dir<Q>(J,0), jy = dir<Q>(J,1), jz = dir<Q>(J,2);
-					return ((uint64_t)zq[jz == 0 ? 0 : jz > 0 ? 1 : 2]*a.Ny+yq[jy == 0 ? 0 : jy > 0 ? 1 : 2])*a.Nx+xq[jx == 0 ? 0 : jx > 0 ? 1 : 2];
-				};
-				uint64_t ji = nb(std::integral_constant<int, i+1>{});
-				if ((a.flags[ji]&TYPE_BO) == TYPE_S) f[v][i] = fmaf(w6, cdot<Q, i+1>(a.u[ji], a.u[a.N+ji], a.u[2ull*a.N+ji]), f[v][i]);
-				ji = nb(std::integral_constant<int, i>{});
-				if ((a.flags[ji]&TYPE_BO) == TYPE_S) f[v][i+1] = fmaf(w6, cdot<Q, i>(a.u[ji], a.u[a.N+ji], a.u[2ull*a.N+ji]), f[v][i+1]);
-			});
-		}
-		collide<Q, COLL, FIELDS_ONLY>(f[v], feat, bo, a, n, rhon[v], uxn[v], uyn[v], uzn[v], wf[v]);
-	}
-
-	// ---- rho/u output (kernel.cpp:1581-1591, 1881-1893)
-	if (FIELDS_ONLY || feat(F_UPDATE_FIELDS)) {
-#pragma unroll
-		for (int v = 0; v < V; v++) if (wf[v]) {
-			const uint64_t n = row0+x+(uint32_t)v;
-			a.rho[n] = rhon[v]; a.u[n] = uxn[v]; a.u[a.N+n] = uyn[v]; a.u[2ull*a.N+n] = uzn[v];
-		}
+	// ---- boundaries, moments, collision
+	if (feat(F_MOVING_BOUNDARIES) && bo == TYPE_MS) apply_moving_boundaries<Q>(f, a, x, yq, zq);
+	float rhon, uxn, uyn, uzn;
+	bool write_fields = false;
+	collide<Q, COLL, FIELDS_ONLY>(f, feat, bo, a, n, rhon, uxn, uyn, uzn, write_fields);
+	if ((FIELDS_ONLY || feat(F_UPDATE_FIELDS)) && write_fields) { // kernel.cpp:1581-1591, 1881-1893
+		a.rho[n] = rhon; a.u[n] = uxn; a.u[a.N+n] = uyn; a.u[2ull*a.N+n] = uzn;
 	}
 	if constexpr (FIELDS_ONLY) return;
 
 	// ---- streaming part 1: scatter to the slots that were read, pair members swapped (kernel.cpp:1339-1345)
-	bool all = true;
-#pragma unroll
-	for (int v = 0; v < V; v++) all = all && active[v];
-	auto put = [&](raw* p, uint32_t xs, auto aligned, const raw* t) {
-		if (all) store_raw<raw, V, decltype(aligned)::value>(p, xs, t);
-		else {
-#pragma unroll
-			for (int v = 0; v < V; v++) if (active[v]) p[xs+(uint32_t)v] = t[v];
-		}
-	};
-	{
-		raw t[V];
-#pragma unroll
-		for (int v = 0; v < V; v++) t[v] = S::encode(f[v][0]);
-		put(fi+row0, x, std::true_type{}, t);
-	}
+	fi[n] = S::encode(f[0]);
 	static_for<1, Q, 2>([&](auto I) {
 		constexpr int i = I, cx = dir<Q>(i,0), cy = dir<Q>(i,1), cz = dir<Q>(i,2);
 		const uint32_t sA = a.odd ? i : i+1, sB = a.odd ? i+1 : i;
-		raw t[V];
-#pragma unroll
-		for (int v = 0; v < V; v++) t[v] = S::encode(f[v][i+1]);
-		put(fi+(uint64_t)sA*a.N+row0, x, std::true_type{}, t);
-#pragma unroll
-		for (int v = 0; v < V; v++) t[v] = S::encode(f[v][i]);
+		fi[(uint64_t)sA*a.N+n] = S::encode(f[i+1]);
 		raw* pn = fi+(uint64_t)sB*a.N+((uint64_t)zq[cz == 0 ? 0 : cz > 0 ? 1 : 2]*a.Ny+yq[cy == 0 ? 0 : cy > 0 ? 1 : 2])*a.Nx;
-		if constexpr (cx == 0) put(pn, x, std::true_type{}, t);
-		else if constexpr (cx > 0) {
-			if (x+(uint32_t)V < a.Nx) put(pn, x+1u, std::false_type{}, t);
-			else {
-#pragma unroll
-				for (int v = 0; v < V; v++) if (active[v]) { const uint32_t xn = x+(uint32_t)v+1u; pn[xn == a.Nx ? 0u : xn] = t[v]; }
-			}
-		} else {
-			if (x > 0u) put(pn, x-1u, std::false_type{}, t);
-			else {
-#pragma unroll
-				for (int v = 0; v < V; v++) if (active[v]) { const uint32_t xv = x+(uint32_t)v; pn[xv == 0u ? a.Nx-1u : xv-1u] = t[v]; }
-			}
-		}
+		pn[cx == 0 ? x : cx > 0 ? xp : xm] = S::encode(f[i]);
 	});
 }
 
@@ -286,21 +183,7 @@ __global__ __launch_bounds__(256) void k_collide_wide(const Args a) {
 			const uint8_t bo = fl[v]&TYPE_BO;
 			float f[Q];
 			static_for<0, Q, 1>([&](auto I) { f[I] = S::decode(d[I][v]); });
-			if (feat(F_MOVING_BOUNDARIES) && bo == TYPE_MS) { // kernel.cpp:1111-1118
-				const uint32_t xq[3] = {xv, xv+1u == a.Nx ? 0u : xv+1u, xv == 0u ? a.Nx-1u : xv-1u};
-				static_for<1, Q, 2>([&](auto I) {
-					constexpr int i = I;
-					constexpr float w6 = -6.0f*weight<Q>(i);
-					auto nb = [&](auto J) -> uint64_t {
-						constexpr int jx = dir<Q>(J,0), jy = dir<Q>(J,1), jz = dir<Q>(J,2);
-						return ((uint64_t)zq[jz == 0 ? 0 : jz > 0 ? 1 : 2]*a.Ny+yq[jy == 0 ? 0 : jy > 0 ? 1 : 2])*a.Nx+xq[jx == 0 ? 0 : jx > 0 ? 1 : 2];
-					};
-					uint64_t ji = nb(std::integral_constant<int, i+1>{});
-					if ((a.flags[ji]&TYPE_BO) == TYPE_S) f[i] = fmaf(w6, cdot<Q, i+1>(a.u[ji], a.u[a.N+ji], a.u[2ull*a.N+ji]), f[i]);
-					ji = nb(std::integral_constant<int, i>{});
-					if ((a.flags[ji]&TYPE_BO) == TYPE_S) f[i+1] = fmaf(w6, cdot<Q, i>(a.u[ji], a.u[a.N+ji], a.u[2ull*a.N+ji]), f[i+1]);
-				});
-			}
+			if (feat(F_MOVING_BOUNDARIES) && bo == TYPE_MS) apply_moving_boundaries<Q>(f, a, xv, yq, zq);
 			float rhon, uxn, uyn, uzn;
 			collide<Q, COLL, false>(f, feat, bo, a, n, rhon, uxn, uyn, uzn, wf[v]);
 			if (feat(F_UPDATE_FIELDS)) { out[0][v] = rhon; out[1][v] = uxn; out[2][v] = uyn; out[3][v] = uzn; }

@@ -351,7 +351,7 @@ static collide_launch_fn find_collide(const lbmhip_domain* d, int V, bool fields
 // Default launch geometry.  Measured on MI355X at 512^3: plain FP32 D3Q19 is fastest with one cell per lane (dword
 // accesses), 256-lane workgroups and at most 12 waves resident per CU (more waves in flight lower the achieved HBM
 // bandwidth by ~15 %); the 16-bit formats with the 4-cells-per-lane kernel (aligned 8-byte accesses); rows that are not a
-// multiple of 4 cells fall back to 2 (FP16S) or 1 (FP16C) cells per lane.  Heavier collision variants (TRT, subgrid,
+// multiple of 4 cells fall back to 2 or 1 cells per lane.  Heavier collision variants (TRT, subgrid,
 // field output) want more waves, which the search below finds on the running lattice.
 static void default_geometry(const lbmhip_domain* d, bool fields_only, int* V_out, int* blocks_per_cu_out) {
 	const bool small = d->cfg.velocity_set == 9u || d->cfg.velocity_set == 15u;
@@ -360,7 +360,6 @@ static void default_geometry(const lbmhip_domain* d, bool fields_only, int* V_ou
 	if (V == 0) V = half ? 4 : d->cfg.velocity_set == 27u ? 2 : 1; // D3Q27 FP32: 27 dword streams per lane leave too little in flight
 	if (small) V = 1;
 	while (V > 1 && d->cfg.Nx%(uint32_t)V != 0u) V /= 2; // vector accesses need rows that are whole vectors
-	if (V == 2 && d->cells_per_thread == 0 && d->cfg.storage == LBMHIP_FP16C) V = 1;
 	int blocks_per_cu = d->blocks_per_cu;
 	if (blocks_per_cu < 0) {
 		if (fields_only) blocks_per_cu = 0;
@@ -383,7 +382,7 @@ static void build_candidates(lbmhip_domain* d) {
 		if ((d->cfg.Nx/(uint32_t)V)%256u != 0u && d->cfg.Nx/(uint32_t)V > 128u) for (int c : ragged_caps) { push(c, 128); push(c, 64); }
 	};
 	if (!half) { add(1, {2, 3, 4, 5, 0}, {3, 0}); add(2, {2, 3, 4, 0}, {2, 3}); add(4, {0, 5}, {}); }
-	else { add(4, {0, 4, 5, 6, 7, 8}, {0, 4}); add(1, {0, 4, 8}, {8}); if (d->cfg.storage == LBMHIP_FP16S) add(2, {0}, {6}); }
+	else { add(4, {0, 4, 5, 6, 7, 8}, {0, 4}); add(2, {0, 6}, {6}); add(1, {0, 4, 8}, {8}); }
 }
 
 static int launch_collide_geometry(lbmhip_domain* d, const Args& base, int V, int blocks_per_cu, int block_lanes, uint32_t z0, uint32_t z1, bool fields_only) {
