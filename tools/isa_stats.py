@@ -39,11 +39,11 @@ def main():
         if m:
             stats[cur][m.group(1)] = int(m.group(2))
     for k, c in stats.items():
-        m = re.match(r"_ZN3lbm9k_collideILi(\d+)ELi(\d+)ELi(\d+)ELi(n?\d+)ELi(\d+)ELb(\d)", k)
+        m = re.match(r"_ZN3lbm9k_collideILi(\d+)ELi(\d+)ELi(\d+)ELi(n?\d+)ELb(\d)", k)
         w = re.match(r"_ZN3lbm14k_collide_wideILi(\d+)ELi(\d+)ELi(\d+)ELi(n?\d+)ELi(\d+)E", k)
         if not (m or w) or c["valu"] < 50:
             continue
-        tag = "Q%s st%s coll%s feat%s V%s fields%s" % m.groups() if m else "Q%s st%s coll%s feat%s V%s wide" % w.groups()
+        tag = "Q%s st%s coll%s feat%s V1 fields%s" % m.groups() if m else "Q%s st%s coll%s feat%s V%s wide" % w.groups()
         if flt in tag:
             print("%-40s valu %4d salu %4d branch %3d load %3d store %3d vgpr %3d occ %d scratch %d" % (
                 tag, c["valu"], c["salu"], c["branch"], c["load"], c["store"], c["NumVgprs"], c["Occupancy"], c["ScratchSize"]))
