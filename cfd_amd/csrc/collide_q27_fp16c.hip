@@ -1,7 +1,7 @@
 // stream_collide / update_fields instances for D3Q27 with FP16C DDF storage (gfx950).
 #include "lbm_dispatch.hpp"
 namespace lbm {
-collide_launch_fn select_collide_q27_fp16c(int COLL, int FEAT, int V, bool FO) {
+collide_launch_fn select_collide_q27_fp16c(int COLL, int FEAT, int V, int P, bool FO) {
 	LBM_GENERIC(27, ST_FP16C)
 	LBM_SPECIALISE(27, ST_FP16C, 0)
 	LBM_SPECIALISE(27, ST_FP16C, F_VOLUME_FORCE|F_FORCE_FIELD)

@@ -74,10 +74,34 @@ template <int Q> __host__ __device__ constexpr int transfer_dir(int axis, int b)
 	else { constexpr int t[3][9] = {{1,7,13,9,15,19,26,21,23},{3,7,14,11,17,19,24,21,25},{5,9,16,11,18,19,22,23,25}}; return t[axis][b]; }
 }
 
+// ---------------------------------------------------------------------------------------------- one cell or a pair of cells
+// The cell arithmetic is written once over a type R: float (one cell) or float2v (two neighbouring cells of a lane).  With
+// float2v the additions, multiplications and fmas become the packed FP32 instructions of gfx90a+ (v_pk_add_f32,
+// v_pk_mul_f32, v_pk_fma_f32: two IEEE results per issue slot); division, square root and min/max have no packed form and
+// are evaluated element by element with the same scalar code as for one cell, so both types give the same bits.
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+template <class R> struct lanes_of { static constexpr int W = 1; };
+template <> struct lanes_of<float2v> { static constexpr int W = 2; };
+__device__ __forceinline__ float fma_(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ float2v fma_(float2v a, float2v b, float2v c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ float div_(float a, float b) { return a/b; }
+__device__ __forceinline__ float2v div_(float2v a, float2v b) { float2v r; r.x = a.x/b.x; r.y = a.y/b.y; return r; }
+__device__ __forceinline__ float sqrt_(float a) { return sqrtf(a); }
+__device__ __forceinline__ float2v sqrt_(float2v a) { float2v r; r.x = sqrtf(a.x); r.y = sqrtf(a.y); return r; }
+__device__ __forceinline__ float get_(float a, int) { return a; }
+__device__ __forceinline__ float get_(float2v a, int k) { return k ? a.y : a.x; }
+__device__ __forceinline__ void set_(float& a, int, float v) { a = v; }
+__device__ __forceinline__ void set_(float2v& a, int k, float v) { if (k) a.y = v; else a.x = v; }
+// m[k] ? a : b per cell
+__device__ __forceinline__ float select_(const bool* m, float a, float b) { return m[0] ? a : b; }
+__device__ __forceinline__ float2v select_(const bool* m, float2v a, float2v b) { float2v r; r.x = m[0] ? a.x : b.x; r.y = m[1] ? a.y : b.y; return r; }
+template <class R> __device__ __forceinline__ R load_(const float* p) { return *reinterpret_cast<const R*>(p); } // p is aligned to sizeof(R)
+
 // c_i . (a,b,c) with zero components skipped, accumulated in x,y,z order
-template <int Q, int I> __device__ __forceinline__ float cdot(float a, float b, float c) {
+template <int Q, int I, class R> __device__ __forceinline__ R cdot(R a, R b, R c) {
 	constexpr int cx = dir<Q>(I,0), cy = dir<Q>(I,1), cz = dir<Q>(I,2);
-	float s = 0.0f;
+	R s = R(0.0f);
 	if constexpr (cx != 0) s = cx > 0 ? a : -a;
 	if constexpr (cy != 0) { if constexpr (cx == 0) s = cy > 0 ? b : -b; else s = cy > 0 ? s+b : s-b; }
 	if constexpr (cz != 0) { if constexpr (cx == 0 && cy == 0) s = cz > 0 ? c : -c; else s = cz > 0 ? s+c : s-c; }
@@ -90,12 +114,22 @@ template <> struct Store<ST_FP32> {
 	using raw = float;
 	static __device__ __forceinline__ float decode(raw r) { return r; }
 	static __device__ __forceinline__ raw encode(float x) { return x; }
+	// two neighbouring cells at once
+	typedef float2v raw2;
+	static __device__ __forceinline__ float2v decode2(raw2 r) { return r; }
+	static __device__ __forceinline__ raw2 encode2(float2v x) { return x; }
+	static __device__ __forceinline__ raw2 merge2(raw2 old, raw2 val, bool keep0, bool keep1) { raw2 r; r.x = keep0 ? old.x : val.x; r.y = keep1 ? old.y : val.y; return r; }
 };
 // FP16S: IEEE half scaled by 2^15 (lbm.cpp:572-575)
 template <> struct Store<ST_FP16S> {
 	using raw = uint16_t;
 	static __device__ __forceinline__ float decode(raw r) { return __half2float(__ushort_as_half(r))*3.0517578E-5f; }
 	static __device__ __forceinline__ raw encode(float x) { return __half_as_ushort(__float2half_rn(x*32768.0f)); }
+	// two neighbouring cells at once: one dword, the first cell in its low half; conversion with v_cvt_pk_f16_f32 (round to nearest even)
+	typedef uint32_t raw2;
+	static __device__ __forceinline__ float2v decode2(raw2 r) { return __builtin_convertvector(__builtin_bit_cast(half2v, r), float2v)*3.0517578E-5f; }
+	static __device__ __forceinline__ raw2 encode2(float2v x) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(x*32768.0f, half2v)); }
+	static __device__ __forceinline__ raw2 merge2(raw2 old, raw2 val, bool keep0, bool keep1) { const uint32_t m = (keep0 ? 0x0000FFFFu : 0u)|(keep1 ? 0xFFFF0000u : 0u); return (old&m)|(val&~m); }
 };
 // FP16C: 1 sign, 4 exponent (bias 15), 11 mantissa bits, subnormals below 2^-14 (kernel.cpp:858-869)
 template <> struct Store<ST_FP16C> {
@@ -114,80 +148,101 @@ template <> struct Store<ST_FP16C> {
 		const uint32_t subnormal = ((((0x007FF800u+(a&0x007FFFFFu))>>((124u-e)&31u))+1u)>>1);
 		return (raw)(((b>>16)&0x8000u)|(e > 112u ? normal : e > 100u ? subnormal : 0u));
 	}
+	typedef uint32_t raw2;
+	static __device__ __forceinline__ float2v decode2(raw2 r) {
+		const uint32_t h0 = r&0xFFFFu, h1 = r>>16;
+		float2v v; v.x = __uint_as_float((h0&0x7FFFu)<<12); v.y = __uint_as_float((h1&0x7FFFu)<<12);
+		v = v*0x1p112f;
+		v.x = __uint_as_float(__float_as_uint(v.x)|((h0&0x8000u)<<16)); v.y = __uint_as_float(__float_as_uint(v.y)|((h1&0x8000u)<<16));
+		return v;
+	}
+	static __device__ __forceinline__ raw2 encode2(float2v x) { return (uint32_t)encode(x.x)|((uint32_t)encode(x.y)<<16); }
+	static __device__ __forceinline__ raw2 merge2(raw2 old, raw2 val, bool keep0, bool keep1) { const uint32_t m = (keep0 ? 0x0000FFFFu : 0u)|(keep1 ? 0xFFFF0000u : 0u); return (old&m)|(val&~m); }
 };
 
 // ---------------------------------------------------------------------------------------------- moments, equilibrium, forcing
 // kernel.cpp:1010-1067 (shifted equilibrium, pair-symmetric nested fma)
-template <int Q> __device__ __forceinline__ void f_eq(float rho, float ux, float uy, float uz, float* feq) {
-	const float rhom1 = rho-1.0f;
-	float c3;
+template <int Q, class R> __device__ __forceinline__ void f_eq(R rho, R ux, R uy, R uz, R* feq) {
+	const R rhom1 = rho-1.0f;
+	R c3;
 	if constexpr (Q == 9) c3 = -3.0f*(ux*ux+uy*uy); else c3 = -3.0f*(ux*ux+uy*uy+uz*uz);
 	ux *= 3.0f; uy *= 3.0f; uz *= 3.0f;
-	feq[0] = weight<Q>(0)*fmaf(rho, 0.5f*c3, rhom1);
+	feq[0] = weight<Q>(0)*fma_(rho, 0.5f*c3, rhom1);
 	static_for<1, Q, 2>([&](auto I) {
 		constexpr int i = I;
-		const float cu = cdot<Q, i>(ux, uy, uz);
-		const float wr = weight<Q>(i)*rho, wm = weight<Q>(i)*rhom1;
-		feq[i]   = fmaf(wr, fmaf(0.5f, fmaf(cu, cu, c3), cu), wm);
-		feq[i+1] = fmaf(wr, fmaf(0.5f, fmaf(cu, cu, c3), -cu), wm);
+		const R cu = cdot<Q, i>(ux, uy, uz);
+		const R wr = weight<Q>(i)*rho, wm = weight<Q>(i)*rhom1;
+		feq[i]   = fma_(wr, fma_(R(0.5f), fma_(cu, cu, c3), cu), wm);
+		feq[i+1] = fma_(wr, fma_(R(0.5f), fma_(cu, cu, c3), -cu), wm);
 	});
 }
 // kernel.cpp:1069-1094 (1 added last; momentum as alternating +/- chain over the pairs in ascending order)
-template <int Q> __device__ __forceinline__ void rho_u(const float* f, float& rhon, float& uxn, float& uyn, float& uzn) {
-	float rho = f[0];
+template <int Q, class R> __device__ __forceinline__ void rho_u(const R* f, R& rhon, R& uxn, R& uyn, R& uzn) {
+	R rho = f[0];
 	static_for<1, Q, 1>([&](auto I) { rho += f[I]; });
 	rho += 1.0f;
-	float m[3] = {0.0f, 0.0f, 0.0f};
+	R m[3] = {R(0.0f), R(0.0f), R(0.0f)};
 	static_for<0, 3, 1>([&](auto K) {
 		constexpr int k = K;
 		bool started = false;
 		static_for<1, Q, 2>([&](auto I) {
 			constexpr int i = I, ck = dir<Q>(i, k);
 			if constexpr (ck != 0) {
-				const float plus = ck > 0 ? f[i] : f[i+1], minus = ck > 0 ? f[i+1] : f[i];
+				const R plus = ck > 0 ? f[i] : f[i+1], minus = ck > 0 ? f[i+1] : f[i];
 				if (!started) { m[k] = plus-minus; started = true; } else { m[k] = m[k]+plus; m[k] = m[k]-minus; }
 			}
 		});
 	});
-	rhon = rho; uxn = m[0]/rho; uyn = m[1]/rho; uzn = m[2]/rho;
+	rhon = rho; uxn = div_(m[0], rho); uyn = div_(m[1], rho); uzn = div_(m[2], rho);
 }
 __device__ __forceinline__ float clamp_c(float x) { return fminf(fmaxf(x, -0.57735027f), 0.57735027f); } // lbm.cpp:507
+__device__ __forceinline__ float2v clamp_c(float2v x) { float2v r; r.x = clamp_c(x.x); r.y = clamp_c(x.y); return r; }
 
 // Guo forcing term of direction I (kernel.cpp:1097-1107)
-template <int Q, int I> __device__ __forceinline__ float forcing_term(float ux, float uy, float uz, float fx, float fy, float fz, float uF) {
+template <int Q, int I, class R> __device__ __forceinline__ R forcing_term(R ux, R uy, R uz, R fx, R fy, R fz, R uF) {
 	if constexpr (I == 0) return 9.0f*weight<Q>(0)*uF;
-	else return 9.0f*weight<Q>(I)*fmaf(cdot<Q, I>(fx, fy, fz), cdot<Q, I>(ux, uy, uz)+0.33333334f, uF);
+	else return 9.0f*weight<Q>(I)*fma_(cdot<Q, I>(fx, fy, fz), cdot<Q, I>(ux, uy, uz)+0.33333334f, uF);
 }
 
-// ---------------------------------------------------------------------------------------------- the collision of one cell
+// ---------------------------------------------------------------------------------------------- the collision of one cell (R = float) or of cells n, n+1 (R = float2v)
 // f[] holds the streamed-in DDFs; on return it holds the post-collision DDFs (kernel.cpp:1497-1651).
-// FEAT is the feature mask (compile-time when the kernel is specialised, run-time otherwise).
-template <int Q, int COLL, bool FIELDS_ONLY, class Feat>
-__device__ __forceinline__ void collide(float* f, const Feat feat, const uint8_t bo, const Args& a, const uint64_t n,
-                                        float& rhon, float& uxn, float& uyn, float& uzn, bool& write_fields) {
-	const bool eq_cell = feat(F_EQUILIBRIUM_BOUNDARIES) && bo == TYPE_E;
-	if (!FIELDS_ONLY && eq_cell) { rhon = a.rho[n]; uxn = a.u[n]; uyn = a.u[a.N+n]; uzn = a.u[2ull*a.N+n]; }
-	else rho_u<Q>(f, rhon, uxn, uyn, uzn);
-	float fxn = a.fx, fyn = a.fy, fzn = a.fz;
-	if (feat(F_FORCE_FIELD)) { fxn += a.F[n]; fyn += a.F[a.N+n]; fzn += a.F[2ull*a.N+n]; }
+// FEAT is the feature mask (compile-time when the kernel is specialised, run-time otherwise); bo[] and write_fields[] have one entry per cell.
+template <int Q, int COLL, bool FIELDS_ONLY, class Feat, class R>
+__device__ __forceinline__ void collide(R* f, const Feat feat, const uint8_t* bo, const Args& a, const uint64_t n,
+                                        R& rhon, R& uxn, R& uyn, R& uzn, bool* write_fields) {
+	constexpr int W = lanes_of<R>::W;
+	bool eq_cell[W];
+#pragma unroll
+	for (int k = 0; k < W; k++) eq_cell[k] = feat(F_EQUILIBRIUM_BOUNDARIES) && bo[k] == TYPE_E;
+	if (W == 1 && !FIELDS_ONLY && eq_cell[0]) { rhon = R(a.rho[n]); uxn = R(a.u[n]); uyn = R(a.u[a.N+n]); uzn = R(a.u[2ull*a.N+n]); }
+	else {
+		rho_u<Q>(f, rhon, uxn, uyn, uzn);
+		if constexpr (W > 1 && !FIELDS_ONLY) {
+#pragma unroll
+			for (int k = 0; k < W; k++) if (eq_cell[k]) { set_(rhon, k, a.rho[n+k]); set_(uxn, k, a.u[n+k]); set_(uyn, k, a.u[a.N+n+k]); set_(uzn, k, a.u[2ull*a.N+n+k]); }
+		}
+	}
+	R fxn = R(a.fx), fyn = R(a.fy), fzn = R(a.fz);
+	if (feat(F_FORCE_FIELD)) { fxn += load_<R>(a.F+n); fyn += load_<R>(a.F+a.N+n); fzn += load_<R>(a.F+2ull*a.N+n); }
 	if (feat(F_VOLUME_FORCE)) {
-		const float rho2 = 0.5f/rhon;
-		uxn = clamp_c(fmaf(fxn, rho2, uxn)); uyn = clamp_c(fmaf(fyn, rho2, uyn)); uzn = clamp_c(fmaf(fzn, rho2, uzn));
+		const R rho2 = div_(R(0.5f), rhon);
+		uxn = clamp_c(fma_(fxn, rho2, uxn)); uyn = clamp_c(fma_(fyn, rho2, uyn)); uzn = clamp_c(fma_(fzn, rho2, uzn));
 	} else {
 		uxn = clamp_c(uxn); uyn = clamp_c(uyn); uzn = clamp_c(uzn);
 	}
-	write_fields = (FIELDS_ONLY || feat(F_UPDATE_FIELDS)) && !eq_cell;
+#pragma unroll
+	for (int k = 0; k < W; k++) write_fields[k] = (FIELDS_ONLY || feat(F_UPDATE_FIELDS)) && !eq_cell[k];
 	if constexpr (FIELDS_ONLY) return;
 
-	float feq[Q];
+	R feq[Q];
 	f_eq<Q>(rhon, uxn, uyn, uzn, feq);
-	float w = a.w;
+	R w = R(a.w);
 	if (feat(F_SUBGRID)) { // Smagorinsky-Lilly (kernel.cpp:1597-1611)
 		const float tau0 = a.tau0; // = 1/w (kernel.cpp:1598)
-		float Hxx = 0.0f, Hyy = 0.0f, Hzz = 0.0f, Hxy = 0.0f, Hxz = 0.0f, Hyz = 0.0f;
+		R Hxx = R(0.0f), Hyy = R(0.0f), Hzz = R(0.0f), Hxy = R(0.0f), Hxz = R(0.0f), Hyz = R(0.0f);
 		static_for<1, Q, 1>([&](auto I) {
 			constexpr int i = I, cx = dir<Q>(i,0), cy = dir<Q>(i,1), cz = dir<Q>(i,2);
-			const float fneq = f[i]-feq[i];
+			const R fneq = f[i]-feq[i];
 			if constexpr (cx != 0) Hxx += fneq;
 			if constexpr (cx*cy != 0) Hxy += cx*cy > 0 ? fneq : -fneq;
 			if constexpr (cy != 0) Hyy += fneq;
@@ -195,38 +250,43 @@ __device__ __forceinline__ void collide(float* f, const Feat feat, const uint8_t
 			if constexpr (cy*cz != 0) Hyz += cy*cz > 0 ? fneq : -fneq;
 			if constexpr (cz != 0) Hzz += fneq;
 		});
-		const float Qn = Hxx*Hxx+Hyy*Hyy+Hzz*Hzz+2.0f*(Hxy*Hxy+Hxz*Hxz+Hyz*Hyz);
-		w = 2.0f/(tau0+sqrtf(tau0*tau0+0.76421222f*sqrtf(Qn)/rhon));
+		const R Qn = Hxx*Hxx+Hyy*Hyy+Hzz*Hzz+2.0f*(Hxy*Hxy+Hxz*Hxz+Hyz*Hyz);
+		w = div_(R(2.0f), tau0+sqrt_(tau0*tau0+div_(0.76421222f*sqrt_(Qn), rhon)));
 	}
 	const bool force = feat(F_VOLUME_FORCE);
-	float uF = 0.0f;
-	if (force) { if constexpr (Q == 9) uF = -0.33333334f*fmaf(uxn, fxn, uyn*fyn); else uF = -0.33333334f*fmaf(uxn, fxn, fmaf(uyn, fyn, uzn*fzn)); }
+	R uF = R(0.0f);
+	if (force) { if constexpr (Q == 9) uF = -0.33333334f*fma_(uxn, fxn, uyn*fyn); else uF = -0.33333334f*fma_(uxn, fxn, fma_(uyn, fyn, uzn*fzn)); }
+	const bool any_eq = feat(F_EQUILIBRIUM_BOUNDARIES);
 	if constexpr (COLL == COLL_SRT) { // kernel.cpp:1613-1622
-		const float c_tau = fmaf(w, -0.5f, 1.0f), omw = 1.0f-w;
+		const R c_tau = fma_(w, R(-0.5f), R(1.0f)), omw = 1.0f-w;
 		static_for<0, Q, 1>([&](auto I) {
 			constexpr int i = I;
-			const float Fin = force ? forcing_term<Q, i>(uxn, uyn, uzn, fxn, fyn, fzn, uF)*c_tau : 0.0f;
-			f[i] = eq_cell ? feq[i] : fmaf(omw, f[i], fmaf(w, feq[i], Fin));
+			const R Fin = force ? forcing_term<Q, i>(uxn, uyn, uzn, fxn, fyn, fzn, uF)*c_tau : R(0.0f);
+			const R fc = fma_(omw, f[i], fma_(w, feq[i], Fin));
+			f[i] = any_eq ? select_(eq_cell, feq[i], fc) : fc;
 		});
 	} else { // TRT (kernel.cpp:1623-1651)
-		const float wp = w, wm = feat(F_SUBGRID) ? 1.0f/(0.1875f/(1.0f/w-0.5f)+0.5f) : a.wm; // without subgrid w is the lattice constant
-		const float c_taup = fmaf(wp, -0.25f, 0.5f), c_taum = fmaf(wm, -0.25f, 0.5f), hwp = 0.5f*wp, hwm = 0.5f*wm;
+		const R wp = w, wm = feat(F_SUBGRID) ? div_(R(1.0f), div_(R(0.1875f), div_(R(1.0f), w)-0.5f)+0.5f) : R(a.wm); // without subgrid w is the lattice constant
+		const R c_taup = fma_(wp, R(-0.25f), R(0.5f)), c_taum = fma_(wm, R(-0.25f), R(0.5f)), hwp = 0.5f*wp, hwm = 0.5f*wm;
 		{
-			const float Fin0 = force ? forcing_term<Q, 0>(uxn, uyn, uzn, fxn, fyn, fzn, uF) : 0.0f;
-			const float F0 = force ? fmaf(c_taup, Fin0+Fin0, c_taum*(Fin0-Fin0)) : 0.0f;
-			f[0] = eq_cell ? feq[0] : fmaf(hwp, feq[0]-f[0]+feq[0]-f[0], fmaf(hwm, feq[0]-feq[0]-f[0]+f[0], f[0]+F0));
+			const R Fin0 = force ? forcing_term<Q, 0>(uxn, uyn, uzn, fxn, fyn, fzn, uF) : R(0.0f);
+			const R F0 = force ? fma_(c_taup, Fin0+Fin0, c_taum*(Fin0-Fin0)) : R(0.0f);
+			const R fc = fma_(hwp, feq[0]-f[0]+feq[0]-f[0], fma_(hwm, feq[0]-feq[0]-f[0]+f[0], f[0]+F0));
+			f[0] = any_eq ? select_(eq_cell, feq[0], fc) : fc;
 		}
 		static_for<1, Q, 2>([&](auto I) {
 			constexpr int i = I, j = I+1;
-			float Fi = 0.0f, Fj = 0.0f;
+			R Fi = R(0.0f), Fj = R(0.0f);
 			if (force) {
-				const float Gi = forcing_term<Q, i>(uxn, uyn, uzn, fxn, fyn, fzn, uF), Gj = forcing_term<Q, j>(uxn, uyn, uzn, fxn, fyn, fzn, uF);
-				Fi = fmaf(c_taup, Gi+Gj, c_taum*(Gi-Gj));
-				Fj = fmaf(c_taup, Gj+Gi, c_taum*(Gj-Gi));
+				const R Gi = forcing_term<Q, i>(uxn, uyn, uzn, fxn, fyn, fzn, uF), Gj = forcing_term<Q, j>(uxn, uyn, uzn, fxn, fyn, fzn, uF);
+				Fi = fma_(c_taup, Gi+Gj, c_taum*(Gi-Gj));
+				Fj = fma_(c_taup, Gj+Gi, c_taum*(Gj-Gi));
 			}
-			const float fi_ = f[i], fj_ = f[j], ei = feq[i], ej = feq[j];
-			f[i] = eq_cell ? ei : fmaf(hwp, ei-fi_+ej-fj_, fmaf(hwm, ei-ej-fi_+fj_, fi_+Fi));
-			f[j] = eq_cell ? ej : fmaf(hwp, ej-fj_+ei-fi_, fmaf(hwm, ej-ei-fj_+fi_, fj_+Fj));
+			const R fi_ = f[i], fj_ = f[j], ei = feq[i], ej = feq[j];
+			const R ci = fma_(hwp, ei-fi_+ej-fj_, fma_(hwm, ei-ej-fi_+fj_, fi_+Fi));
+			const R cj = fma_(hwp, ej-fj_+ei-fi_, fma_(hwm, ej-ei-fj_+fi_, fj_+Fj));
+			f[i] = any_eq ? select_(eq_cell, ei, ci) : ci;
+			f[j] = any_eq ? select_(eq_cell, ej, cj) : cj;
 		});
 	}
 }

@@ -13,35 +13,36 @@ hipError_t launch_collide(const Args& a, dim3 grid, dim3 block, uint32_t lds_byt
 	return hipGetLastError();
 }
 
-template <int Q, int ST, int COLL, int FEAT, int V>
+template <int Q, int ST, int COLL, int FEAT, int V, int P>
 hipError_t launch_collide_wide(const Args& a, dim3 grid, dim3 block, uint32_t lds_bytes, hipStream_t stream) {
-	hipLaunchKernelGGL((k_collide_wide<Q, ST, COLL, FEAT, V>), grid, block, lds_bytes, stream, a);
+	hipLaunchKernelGGL((k_collide_wide<Q, ST, COLL, FEAT, V, P>), grid, block, lds_bytes, stream, a);
 	return hipGetLastError();
 }
 
 // FEAT < 0 selects the instance that reads the feature mask at run time; FO = update_fields (always run-time features, V=1)
-template <int Q, int ST, int COLL, int FEAT> collide_launch_fn pick_v(int V) {
+// V = cells per lane; P = 2 selects the instance that collides two cells at a time in packed arithmetic (V = 2 or 4 only)
+template <int Q, int ST, int COLL, int FEAT> collide_launch_fn pick_v(int V, int P) {
 	switch (V) {
-		case 4: return launch_collide_wide<Q, ST, COLL, FEAT, 4>;
-		case 2: return launch_collide_wide<Q, ST, COLL, FEAT, 2>;
+		case 4: return P == 2 ? launch_collide_wide<Q, ST, COLL, FEAT, 4, 2> : launch_collide_wide<Q, ST, COLL, FEAT, 4, 1>;
+		case 2: return P == 2 ? launch_collide_wide<Q, ST, COLL, FEAT, 2, 2> : launch_collide_wide<Q, ST, COLL, FEAT, 2, 1>;
 		default: return launch_collide<Q, ST, COLL, FEAT, false>;
 	}
 }
 
 // per translation unit: returns nullptr when (COLL, FEAT) has no compiled instance
-collide_launch_fn select_collide_q19_fp32(int COLL, int FEAT, int V, bool FO);
-collide_launch_fn select_collide_q19_fp16s(int COLL, int FEAT, int V, bool FO);
-collide_launch_fn select_collide_q19_fp16c(int COLL, int FEAT, int V, bool FO);
-collide_launch_fn select_collide_q27_fp32(int COLL, int FEAT, int V, bool FO);
-collide_launch_fn select_collide_q27_fp16s(int COLL, int FEAT, int V, bool FO);
-collide_launch_fn select_collide_q27_fp16c(int COLL, int FEAT, int V, bool FO);
-collide_launch_fn select_collide_small(int Q, int ST, int COLL, int FEAT, int V, bool FO); // D2Q9, D3Q15
+collide_launch_fn select_collide_q19_fp32(int COLL, int FEAT, int V, int P, bool FO);
+collide_launch_fn select_collide_q19_fp16s(int COLL, int FEAT, int V, int P, bool FO);
+collide_launch_fn select_collide_q19_fp16c(int COLL, int FEAT, int V, int P, bool FO);
+collide_launch_fn select_collide_q27_fp32(int COLL, int FEAT, int V, int P, bool FO);
+collide_launch_fn select_collide_q27_fp16s(int COLL, int FEAT, int V, int P, bool FO);
+collide_launch_fn select_collide_q27_fp16c(int COLL, int FEAT, int V, int P, bool FO);
+collide_launch_fn select_collide_small(int Q, int ST, int COLL, int FEAT, int V, int P, bool FO); // D2Q9, D3Q15
 
 // LBM_SELECT_BODY(Q, ST, specialised feature masks...) expands to the body of one select_collide_* function
 #define LBM_SPECIALISE(Q, ST, MASK) \
-	if (FEAT == (MASK)) return COLL == COLL_TRT ? pick_v<Q, ST, COLL_TRT, (MASK)>(V) : pick_v<Q, ST, COLL_SRT, (MASK)>(V);
+	if (FEAT == (MASK)) return COLL == COLL_TRT ? pick_v<Q, ST, COLL_TRT, (MASK)>(V, P) : pick_v<Q, ST, COLL_SRT, (MASK)>(V, P);
 #define LBM_GENERIC(Q, ST) \
 	if (FO) return COLL == COLL_TRT ? launch_collide<Q, ST, COLL_TRT, -1, true> : launch_collide<Q, ST, COLL_SRT, -1, true>; \
-	if (FEAT < 0) return COLL == COLL_TRT ? pick_v<Q, ST, COLL_TRT, -1>(V) : pick_v<Q, ST, COLL_SRT, -1>(V);
+	if (FEAT < 0) return COLL == COLL_TRT ? pick_v<Q, ST, COLL_TRT, -1>(V, P) : pick_v<Q, ST, COLL_SRT, -1>(V, P);
 
 } // namespace lbm

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void k_collide(const Args a) {
 	if (feat(F_MOVING_BOUNDARIES) && bo == TYPE_MS) apply_moving_boundaries<Q>(f, a, x, yq, zq);
 	float rhon, uxn, uyn, uzn;
 	bool write_fields = false;
-	collide<Q, COLL, FIELDS_ONLY>(f, feat, bo, a, n, rhon, uxn, uyn, uzn, write_fields);
+	collide<Q, COLL, FIELDS_ONLY>(f, feat, &bo, a, n, rhon, uxn, uyn, uzn, &write_fields);
 	if ((FIELDS_ONLY || feat(F_UPDATE_FIELDS)) && write_fields) { // kernel.cpp:1581-1591, 1881-1893
 		a.rho[n] = rhon; a.u[n] = uxn; a.u[a.N+n] = uyn; a.u[2ull*a.N+n] = uzn;
 	}
@@ -85,6 +85,20 @@ __global__ __launch_bounds__(256) void k_collide(const Args a) {
 	});
 }
 
+// elements v, v+1 of a V-element raw vector as one pair (16-bit formats: one dword; FP32: two floats)
+template <class raw2, int V, class rvec> __device__ __forceinline__ raw2 pair_of(const rvec& d, const int v) {
+	if constexpr (sizeof(raw2) == 4) { // 16-bit elements
+		if constexpr (V == 2) return __builtin_bit_cast(uint32_t, d);
+		else { typedef uint32_t wvec __attribute__((ext_vector_type(V/2))); return __builtin_bit_cast(wvec, d)[v/2]; }
+	} else { raw2 r; r.x = d[v]; r.y = d[v+1]; return r; }
+}
+template <class raw2, int V, class rvec> __device__ __forceinline__ void set_pair(rvec& d, const int v, const raw2 p) {
+	if constexpr (sizeof(raw2) == 4) {
+		if constexpr (V == 2) d = __builtin_bit_cast(rvec, p);
+		else { typedef uint32_t wvec __attribute__((ext_vector_type(V/2))); wvec w = __builtin_bit_cast(wvec, d); w[v/2] = p; d = __builtin_bit_cast(rvec, w); }
+	} else { d[v] = p.x; d[v+1] = p.y; }
+}
+
 // ---------------------------------------------------------------------------------------------- stream_collide, V cells per lane, aligned vectors only
 // Same result as k_collide<...,false>, arranged for the memory system: a lane owns V consecutive cells and every stream
 // moves as aligned V*sizeof(raw)-byte vectors (4 cells of 16-bit DDFs: 512 contiguous bytes per wave instruction).  A slot stream that belongs
@@ -95,11 +109,14 @@ __global__ __launch_bounds__(256) void k_collide(const Args a) {
 // update in memory), which keeps the register count near that of one cell.  A skipped cell (solid, halo) keeps the bits
 // that were read and they are written back unchanged: every slot has exactly one owner cell per step (kernel.cpp:1332-1345),
 // so nothing else touches them in between.  Waves without any active cell leave before loading anything.
-template <int Q, int ST, int COLL, int FEAT, int V>
+// P = 1: the V cells are collided one after the other; P = 2: two at a time in packed FP32 arithmetic (half the vector
+// arithmetic instructions, twice the live registers) - same bits either way.
+template <int Q, int ST, int COLL, int FEAT, int V, int P>
 __global__ __launch_bounds__(256) void k_collide_wide(const Args a) {
 	using S = Store<ST>;
 	using raw = typename S::raw;
 	static_assert(V == 2 || V == 4, "vectors of 2 or 4 cells");
+	static_assert(P == 1 || P == 2, "cells collided together");
 	typedef raw rvec __attribute__((ext_vector_type(V)));
 	typedef uint8_t fvec __attribute__((ext_vector_type(V)));
 	typedef typename std::conditional<sizeof(raw) == 2, uint32_t, raw>::type lane_t; // what travels through a wave shuffle
@@ -176,24 +193,62 @@ __global__ __launch_bounds__(256) void k_collide_wide(const Args a) {
 #pragma unroll
 	for (int v = 0; v < V; v++) wf[v] = false;
 #pragma unroll
-	for (int v = 0; v < V; v++) {
-		if (active[v]) {
-			const uint32_t xv = x+(uint32_t)v;
-			const uint64_t n = row0+xv;
-			const uint8_t bo = fl[v]&TYPE_BO;
-			float f[Q];
-			static_for<0, Q, 1>([&](auto I) { f[I] = S::decode(d[I][v]); });
-			if (feat(F_MOVING_BOUNDARIES) && bo == TYPE_MS) apply_moving_boundaries<Q>(f, a, xv, yq, zq);
-			float rhon, uxn, uyn, uzn;
-			collide<Q, COLL, false>(f, feat, bo, a, n, rhon, uxn, uyn, uzn, wf[v]);
-			if (feat(F_UPDATE_FIELDS)) { out[0][v] = rhon; out[1][v] = uxn; out[2][v] = uyn; out[3][v] = uzn; }
-			// streaming part 1 in registers: the slot that held f[i] receives f[i+1] and vice versa (kernel.cpp:1339-1345)
-			d[0][v] = S::encode(f[0]);
-			static_for<1, Q, 2>([&](auto I) {
-				constexpr int i = I;
-				d[i][v] = S::encode(f[i+1]);
-				d[i+1][v] = S::encode(f[i]);
-			});
+	for (int v = 0; v < V; v += P) {
+		if constexpr (P == 1) {
+			if (active[v]) {
+				const uint32_t xv = x+(uint32_t)v;
+				const uint64_t n = row0+xv;
+				const uint8_t bo = fl[v]&TYPE_BO;
+				float f[Q];
+				static_for<0, Q, 1>([&](auto I) { f[I] = S::decode(d[I][v]); });
+				if (feat(F_MOVING_BOUNDARIES) && bo == TYPE_MS) apply_moving_boundaries<Q>(f, a, xv, yq, zq);
+				float rhon, uxn, uyn, uzn;
+				collide<Q, COLL, false>(f, feat, &bo, a, n, rhon, uxn, uyn, uzn, &wf[v]);
+				if (feat(F_UPDATE_FIELDS)) { out[0][v] = rhon; out[1][v] = uxn; out[2][v] = uyn; out[3][v] = uzn; }
+				// streaming part 1 in registers: the slot that held f[i] receives f[i+1] and vice versa (kernel.cpp:1339-1345)
+				d[0][v] = S::encode(f[0]);
+				static_for<1, Q, 2>([&](auto I) {
+					constexpr int i = I;
+					d[i][v] = S::encode(f[i+1]);
+					d[i+1][v] = S::encode(f[i]);
+				});
+			}
+		} else {
+			if (active[v] || active[v+1]) { // an inactive partner is computed along and its result dropped
+				const uint32_t xv = x+(uint32_t)v;
+				const uint64_t n = row0+xv;
+				const uint8_t bo[2] = {(uint8_t)(fl[v]&TYPE_BO), (uint8_t)(fl[v+1]&TYPE_BO)};
+				float2v f[Q];
+				static_for<0, Q, 1>([&](auto I) { f[I] = S::decode2(pair_of<typename S::raw2, V>(d[I], v)); });
+				if (feat(F_MOVING_BOUNDARIES) && (bo[0] == TYPE_MS || bo[1] == TYPE_MS)) {
+#pragma unroll
+					for (int k = 0; k < 2; k++) if (bo[k] == TYPE_MS) {
+						float fk[Q];
+						static_for<0, Q, 1>([&](auto I) { fk[I] = get_(f[I], k); });
+						apply_moving_boundaries<Q>(fk, a, xv+(uint32_t)k, yq, zq);
+						static_for<0, Q, 1>([&](auto I) { set_(f[I], k, fk[I]); });
+					}
+				}
+				float2v rhon, uxn, uyn, uzn;
+				collide<Q, COLL, false>(f, feat, bo, a, n, rhon, uxn, uyn, uzn, &wf[v]);
+				wf[v] = wf[v] && active[v]; wf[v+1] = wf[v+1] && active[v+1];
+				if (feat(F_UPDATE_FIELDS)) {
+					out[0][v] = rhon.x; out[1][v] = uxn.x; out[2][v] = uyn.x; out[3][v] = uzn.x;
+					out[0][v+1] = rhon.y; out[1][v+1] = uxn.y; out[2][v+1] = uyn.y; out[3][v+1] = uzn.y;
+				}
+				// streaming part 1 in registers (kernel.cpp:1339-1345); an inactive cell keeps the bits that were read
+				const bool keep0 = !active[v], keep1 = !active[v+1];
+				auto put = [&](auto I, const float2v val) {
+					const typename S::raw2 e = S::encode2(val);
+					set_pair<typename S::raw2, V>(d[I], v, S::merge2(pair_of<typename S::raw2, V>(d[I], v), e, keep0, keep1));
+				};
+				put(std::integral_constant<int, 0>{}, f[0]);
+				static_for<1, Q, 2>([&](auto I) {
+					constexpr int i = I;
+					put(std::integral_constant<int, i>{}, f[i+1]);
+					put(std::integral_constant<int, i+1>{}, f[i]);
+				});
+			}
 		}
 		__builtin_amdgcn_sched_barrier(0); // keep the cells apart: interleaving them multiplies the live registers
 	}

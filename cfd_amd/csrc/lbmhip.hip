@@ -36,10 +36,10 @@ struct lbmhip_domain {
 	void* halo[4];
 	uint64_t halo_capacity;
 	hipEvent_t ev_start, ev_stop, ev_packed, ev_copied;
-	int cells_per_thread, block, blocks_per_cu;
+	int cells_per_thread, cells_together, block, blocks_per_cu;
 	// launch-geometry search over the first full-lattice stream_collide launches (results do not depend on the geometry)
-	struct { int V, blocks_per_cu, block; float ms; } cand[48];
-	int ncand, tune_launches, tune_pending, autotune, tuned, tuned_V, tuned_blocks_per_cu, tuned_block;
+	struct { int V, P, blocks_per_cu, block; float ms; } cand[64];
+	int ncand, tune_launches, tune_pending, autotune, tuned, tuned_V, tuned_P, tuned_blocks_per_cu, tuned_block;
 	hipEvent_t ev_tune0, ev_tune1;
 	void* partial; // per-workgroup partial sums of the object_* reductions (kObjectSumBlocks float4)
 	float w;
@@ -157,6 +157,7 @@ int lbmhip_domain_create(const lbmhip_config* c, lbmhip_domain** out) {
 	d->fpxx_bytes = storage_bytes(c->storage);
 	d->w = 1.0f/(3.0f*c->nu+0.5f); // relaxation rate, float like LBM_Domain::get_tau (lbm.hpp:132, lbm.cpp:509-511)
 	d->cells_per_thread = 0; // 0 = automatic
+	d->cells_together = 0;
 	d->block = 0;
 	d->blocks_per_cu = -1; // -1 = automatic
 	d->tune_pending = -1;
@@ -318,6 +319,7 @@ int lbmhip_field_pointer(lbmhip_domain* d, int field, void** p, uint64_t* bytes)
 int lbmhip_set_tuning(lbmhip_domain* d, const char* key, int value) {
 	NEED(d && key, "null argument");
 	if (!strcmp(key, "cells_per_thread")) { NEED(value == 0 || value == 1 || value == 2 || value == 4, "cells_per_thread must be 0 (auto), 1, 2 or 4"); d->cells_per_thread = value; return 0; }
+	if (!strcmp(key, "cells_together")) { NEED(value == 0 || value == 1 || value == 2, "cells_together must be 0 (auto), 1 or 2"); d->cells_together = value; return 0; }
 	if (!strcmp(key, "blocks_per_cu")) { NEED(value >= -1 && value <= 32, "blocks_per_cu must be -1 (auto), 0 (no limit) or 1..32"); d->blocks_per_cu = value; return 0; }
 	if (!strcmp(key, "block")) { NEED(value == 0 || (value >= 64 && value <= 256 && value%64 == 0), "block must be 0 (auto), 64, 128, 192 or 256"); d->block = value; return 0; }
 	if (!strcmp(key, "autotune")) { NEED(value == 0 || value == 1, "autotune must be 0 or 1"); d->autotune = value; if (!value) { d->tuned = 0; d->tune_launches = 0; d->tune_pending = -1; } return 0; }
@@ -326,6 +328,7 @@ int lbmhip_set_tuning(lbmhip_domain* d, const char* key, int value) {
 int lbmhip_get_tuning(lbmhip_domain* d, const char* key, int* value) {
 	NEED(d && key && value, "null argument");
 	if (!strcmp(key, "cells_per_thread")) { *value = d->tuned ? d->tuned_V : d->cells_per_thread; return 0; }
+	if (!strcmp(key, "cells_together")) { *value = d->tuned ? d->tuned_P : d->cells_together; return 0; }
 	if (!strcmp(key, "blocks_per_cu")) { *value = d->tuned ? d->tuned_blocks_per_cu : d->blocks_per_cu; return 0; }
 	if (!strcmp(key, "block")) { *value = d->tuned ? d->tuned_block : d->block; return 0; }
 	if (!strcmp(key, "autotune")) { *value = d->autotune; return 0; }
@@ -336,14 +339,14 @@ int lbmhip_get_tuning(lbmhip_domain* d, const char* key, int* value) {
 } // extern "C"
 
 // ---------------------------------------------------------------------------------------------- launches
-static collide_launch_fn find_collide(const lbmhip_domain* d, int V, bool fields_only) {
+static collide_launch_fn find_collide(const lbmhip_domain* d, int V, int P, bool fields_only) {
 	const int Q = (int)d->cfg.velocity_set, ST = (int)d->cfg.storage, COLL = (int)d->cfg.collision;
 	collide_launch_fn fn = nullptr;
 	for (int pass = 0; pass < 2 && !fn; pass++) { // pass 0: instance specialised for exactly this feature set; pass 1: run-time features
 		const int FEAT = (pass == 0 && !fields_only) ? (int)d->cfg.features : -1;
-		if (Q == 19) fn = ST == ST_FP32 ? select_collide_q19_fp32(COLL, FEAT, V, fields_only) : ST == ST_FP16S ? select_collide_q19_fp16s(COLL, FEAT, V, fields_only) : select_collide_q19_fp16c(COLL, FEAT, V, fields_only);
-		else if (Q == 27) fn = ST == ST_FP32 ? select_collide_q27_fp32(COLL, FEAT, V, fields_only) : ST == ST_FP16S ? select_collide_q27_fp16s(COLL, FEAT, V, fields_only) : select_collide_q27_fp16c(COLL, FEAT, V, fields_only);
-		else fn = select_collide_small(Q, ST, COLL, FEAT, V, fields_only);
+		if (Q == 19) fn = ST == ST_FP32 ? select_collide_q19_fp32(COLL, FEAT, V, P, fields_only) : ST == ST_FP16S ? select_collide_q19_fp16s(COLL, FEAT, V, P, fields_only) : select_collide_q19_fp16c(COLL, FEAT, V, P, fields_only);
+		else if (Q == 27) fn = ST == ST_FP32 ? select_collide_q27_fp32(COLL, FEAT, V, P, fields_only) : ST == ST_FP16S ? select_collide_q27_fp16s(COLL, FEAT, V, P, fields_only) : select_collide_q27_fp16c(COLL, FEAT, V, P, fields_only);
+		else fn = select_collide_small(Q, ST, COLL, FEAT, V, P, fields_only);
 	}
 	return fn;
 }
@@ -353,7 +356,7 @@ static collide_launch_fn find_collide(const lbmhip_domain* d, int V, bool fields
 // bandwidth by ~15 %); the 16-bit formats with the 4-cells-per-lane kernel (aligned 8-byte accesses); rows that are not a
 // multiple of 4 cells fall back to 2 or 1 cells per lane.  Heavier collision variants (TRT, subgrid,
 // field output) want more waves, which the search below finds on the running lattice.
-static void default_geometry(const lbmhip_domain* d, bool fields_only, int* V_out, int* blocks_per_cu_out) {
+static void default_geometry(const lbmhip_domain* d, bool fields_only, int* V_out, int* P_out, int* blocks_per_cu_out) {
 	const bool small = d->cfg.velocity_set == 9u || d->cfg.velocity_set == 15u;
 	const bool half = d->cfg.storage != LBMHIP_FP32;
 	int V = fields_only ? 1 : d->cells_per_thread;
@@ -366,7 +369,7 @@ static void default_geometry(const lbmhip_domain* d, bool fields_only, int* V_ou
 		else if (!half) blocks_per_cu = d->cfg.velocity_set == 27u ? 4 : 3;
 		else blocks_per_cu = (d->cfg.storage == LBMHIP_FP16S && d->cfg.velocity_set == 19u && V == 4) ? 7 : 0;
 	}
-	*V_out = V; *blocks_per_cu_out = blocks_per_cu;
+	*V_out = V; *P_out = (V > 1 && d->cells_together == 2) ? 2 : 1; *blocks_per_cu_out = blocks_per_cu;
 }
 
 // the geometries worth trying for this domain (blocks_per_cu counts 256-lane workgroups)
@@ -374,18 +377,20 @@ static void build_candidates(lbmhip_domain* d) {
 	const bool small = d->cfg.velocity_set == 9u || d->cfg.velocity_set == 15u;
 	const bool half = d->cfg.storage != LBMHIP_FP32;
 	d->ncand = 0;
-	auto add = [&](int V, std::initializer_list<int> caps, std::initializer_list<int> ragged_caps) {
+	auto add = [&](int V, int P, std::initializer_list<int> caps, std::initializer_list<int> ragged_caps) {
 		if (V > 1 && (small || d->cfg.Nx%(uint32_t)V != 0u)) return;
-		auto push = [&](int c, int block) { if (d->ncand < 48) { d->cand[d->ncand].V = V; d->cand[d->ncand].blocks_per_cu = c; d->cand[d->ncand].block = block; d->cand[d->ncand].ms = 1e30f; d->ncand++; } };
+		auto push = [&](int c, int block) { if (d->ncand < 64) { d->cand[d->ncand].V = V; d->cand[d->ncand].P = P; d->cand[d->ncand].blocks_per_cu = c; d->cand[d->ncand].block = block; d->cand[d->ncand].ms = 1e30f; d->ncand++; } };
 		for (int c : caps) push(c, 0);
 		// rows that do not fill whole 256-lane workgroups: smaller workgroups waste fewer lanes at the row end
 		if ((d->cfg.Nx/(uint32_t)V)%256u != 0u && d->cfg.Nx/(uint32_t)V > 128u) for (int c : ragged_caps) { push(c, 128); push(c, 64); }
 	};
-	if (!half) { add(1, {2, 3, 4, 5, 0}, {3, 0}); add(2, {2, 3, 4, 0}, {2, 3}); add(4, {0, 5}, {}); }
-	else { add(4, {0, 4, 5, 6, 7, 8}, {0, 4}); add(2, {0, 6}, {6}); add(1, {0, 4, 8}, {8}); }
+	// P = 2 (two cells at a time in packed arithmetic): a third fewer vector instructions, 1.3-1.6x the registers, so the
+	// register file already limits the waves per CU; +10 % for the arithmetic-heavy variants with 16-bit DDFs
+	if (!half) { add(1, 1, {2, 3, 4, 5, 0}, {3, 0}); add(2, 1, {2, 3, 4, 0}, {2, 3}); add(4, 1, {0, 5}, {}); add(2, 2, {3, 0}, {}); }
+	else { add(4, 1, {0, 4, 5, 6, 7, 8}, {0, 4}); add(2, 1, {0, 6}, {6}); add(1, 1, {0, 4, 8}, {8}); add(4, 2, {0, 4}, {0}); add(2, 2, {0}, {}); }
 }
 
-static int launch_collide_geometry(lbmhip_domain* d, const Args& base, int V, int blocks_per_cu, int block_lanes, uint32_t z0, uint32_t z1, bool fields_only) {
+static int launch_collide_geometry(lbmhip_domain* d, const Args& base, int V, int P, int blocks_per_cu, int block_lanes, uint32_t z0, uint32_t z1, bool fields_only) {
 	const uint32_t lanes_per_row = (d->cfg.Nx+(uint32_t)V-1u)/(uint32_t)V;
 	uint32_t block = block_lanes ? (uint32_t)block_lanes : 256u;
 	const uint32_t need = (lanes_per_row+63u)/64u*64u;
@@ -397,7 +402,7 @@ static int launch_collide_geometry(lbmhip_domain* d, const Args& base, int V, in
 	// one grid dimension carries at most 2^32-1 work-items: x-chunks and y go to grid.x, lattice planes to grid.y
 	const uint64_t blocks_x = (uint64_t)a.xchunks*d->cfg.Ny;
 	NEED(blocks_x*block < 0xFFFFFFFFull && (z1-z0) <= 65535u, "lattice too large for one launch (%llu x %u workgroups)", (unsigned long long)blocks_x, z1-z0);
-	collide_launch_fn fn = find_collide(d, V, fields_only);
+	collide_launch_fn fn = find_collide(d, V, P, fields_only);
 	NEED(fn, "no compiled kernel for D?Q%u storage %u collision %u", d->cfg.velocity_set, d->cfg.storage, d->cfg.collision);
 	// dynamic LDS is not used by the kernel; reserving it caps the workgroups resident per CU (160 KiB LDS per CU)
 	const uint32_t lds = blocks_per_cu > 0 ? ((160u*1024u/(uint32_t)blocks_per_cu)&~255u) : 0u;
@@ -412,17 +417,17 @@ static int launch_collide_planes(lbmhip_domain* d, uint64_t t, float fx, float f
 	if (z0 >= z1) return 0;
 	const Args a = make_args(d, t, fx, fy, fz);
 	DeviceGuard g(d->cfg.device);
-	int V, blocks_per_cu;
-	default_geometry(d, fields_only, &V, &blocks_per_cu);
-	const bool user_set = d->cells_per_thread != 0 || d->blocks_per_cu >= 0 || d->block != 0;
-	if (fields_only || user_set || !d->autotune) return launch_collide_geometry(d, a, V, blocks_per_cu, d->block, z0, z1, fields_only);
-	if (d->tuned) return launch_collide_geometry(d, a, d->tuned_V, d->tuned_blocks_per_cu, d->tuned_block, z0, z1, false);
+	int V, P, blocks_per_cu;
+	default_geometry(d, fields_only, &V, &P, &blocks_per_cu);
+	const bool user_set = d->cells_per_thread != 0 || d->cells_together != 0 || d->blocks_per_cu >= 0 || d->block != 0;
+	if (fields_only || user_set || !d->autotune) return launch_collide_geometry(d, a, V, P, blocks_per_cu, d->block, z0, z1, fields_only);
+	if (d->tuned) return launch_collide_geometry(d, a, d->tuned_V, d->tuned_P, d->tuned_blocks_per_cu, d->tuned_block, z0, z1, false);
 
 	// Geometry search: every full-lattice launch of the first 2*ncand steps runs one candidate between two events; all
 	// candidates compute the same bits, so the search is invisible in the results.  Lattices too small to time are left alone.
 	const uint64_t cells = (uint64_t)d->cfg.Nx*d->cfg.Ny*(z1-z0);
 	const bool searchable = d->N >= (1ull<<21) && 4u*(uint64_t)(z1-z0) >= 3u*(uint64_t)(d->cfg.Nz-2u*hz) && cells > 0u;
-	if (!searchable) return launch_collide_geometry(d, a, V, blocks_per_cu, 0, z0, z1, false);
+	if (!searchable) return launch_collide_geometry(d, a, V, P, blocks_per_cu, 0, z0, z1, false);
 	if (d->ncand == 0) build_candidates(d);
 	if (d->tune_pending >= 0) { // collect the previous candidate's time
 		float ms = 0.0f;
@@ -433,13 +438,13 @@ static int launch_collide_planes(lbmhip_domain* d, uint64_t t, float fx, float f
 		if (d->tune_launches >= 2*d->ncand) {
 			int best = 0;
 			for (int k = 1; k < d->ncand; k++) if (d->cand[k].ms < d->cand[best].ms) best = k;
-			d->tuned_V = d->cand[best].V; d->tuned_blocks_per_cu = d->cand[best].blocks_per_cu; d->tuned_block = d->cand[best].block; d->tuned = 1;
-			return launch_collide_geometry(d, a, d->tuned_V, d->tuned_blocks_per_cu, d->tuned_block, z0, z1, false);
+			d->tuned_V = d->cand[best].V; d->tuned_P = d->cand[best].P; d->tuned_blocks_per_cu = d->cand[best].blocks_per_cu; d->tuned_block = d->cand[best].block; d->tuned = 1;
+			return launch_collide_geometry(d, a, d->tuned_V, d->tuned_P, d->tuned_blocks_per_cu, d->tuned_block, z0, z1, false);
 		}
 	}
 	const int k = d->tune_launches%d->ncand;
 	HIP_TRY(hipEventRecord(d->ev_tune0, d->stream));
-	const int status = launch_collide_geometry(d, a, d->cand[k].V, d->cand[k].blocks_per_cu, d->cand[k].block, z0, z1, false);
+	const int status = launch_collide_geometry(d, a, d->cand[k].V, d->cand[k].P, d->cand[k].blocks_per_cu, d->cand[k].block, z0, z1, false);
 	if (status) return status;
 	HIP_TRY(hipEventRecord(d->ev_tune1, d->stream));
 	d->tune_pending = k;

@@ -239,7 +239,7 @@ class LBM:
         return path
 
     def get_tuning(self, key):
-        """Launch setting of the first domain ("cells_per_thread", "blocks_per_cu", "block", "autotune", "tuned")."""
+        """Launch setting of the first domain ("cells_per_thread", "cells_together", "blocks_per_cu", "block", "autotune", "tuned")."""
         v = C.c_int()
         check(self._L.lbmhip_get_tuning(self.domains[0].h, key.encode(), C.byref(v)))
         return v.value

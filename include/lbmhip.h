@@ -154,15 +154,16 @@ int lbmhip_object_sum(lbmhip_domain* domain, int what, uint8_t flag_marker, cons
 int lbmhip_timer_start(lbmhip_domain* domain);
 int lbmhip_timer_stop(lbmhip_domain* domain, float* milliseconds); /* waits for the stream */
 
-/* ---- tuning knobs (no counterpart in the reference): "cells_per_thread" (0 = auto, 1, 2, 4), "block" (0 = auto,
- * 64..256 threads), "blocks_per_cu" (-1 = auto, 0 = no limit; caps the workgroups resident per compute unit, counted in
- * 256-lane workgroups), "autotune" (1 = default: while all three knobs are on auto, the first full-lattice
+/* ---- tuning knobs (no counterpart in the reference): "cells_per_thread" (0 = auto, 1, 2, 4), "cells_together" (0 = auto,
+ * 1 = a lane collides its cells one after the other, 2 = two at a time in packed FP32 arithmetic; only with 2 or 4 cells
+ * per thread), "block" (0 = auto, 64..256 threads), "blocks_per_cu" (-1 = auto, 0 = no limit; caps the workgroups resident
+ * per compute unit, counted in 256-lane workgroups), "autotune" (1 = default: while all these knobs are on auto, the first full-lattice
  * stream_collide launches of a lattice of at least 2^21 cells each try one launch geometry between two events and the
  * fastest is kept; every geometry computes the same bits.  0 = fixed defaults; the environment variable
  * LBMHIP_AUTOTUNE=0 has the same effect for every domain created afterwards) */
 int lbmhip_set_tuning(lbmhip_domain* domain, const char* key, int value);
-/* Reads back a launch setting ("cells_per_thread", "blocks_per_cu", "block", "autotune") or "tuned" (1 once the geometry
- * search has finished; cells_per_thread / blocks_per_cu then report its choice).  No counterpart in the reference. */
+/* Reads back a launch setting ("cells_per_thread", "cells_together", "blocks_per_cu", "block", "autotune") or "tuned" (1 once
+ * the geometry search has finished; the launch settings then report its choice).  No counterpart in the reference. */
 int lbmhip_get_tuning(lbmhip_domain* domain, const char* key, int* value);
 
 #ifdef __cplusplus

@@ -57,14 +57,16 @@ def test_parity_against_oracle(gpu, name):
         a.close()
 
 
-@pytest.mark.parametrize("cells_per_thread", [1, 2, 4])
+@pytest.mark.parametrize("cells_per_thread,cells_together", [(1, 1), (2, 1), (4, 1), (2, 2), (4, 2)])
 @pytest.mark.parametrize("name", ["tgv32_fp32_srt", "cavity32_fp32_srt", "gui_fp16s_srt", "q27_fp16c_force", "all_fp32_srt_8dom", "all_fp16s_trt_2dom", "q19_fp16c_srt"])
-def test_vector_widths_agree(gpu, name, cells_per_thread):
+def test_vector_widths_agree(gpu, name, cells_per_thread, cells_together):
+    """Every kernel geometry computes the same bits: 1, 2 or 4 cells per lane, collided one at a time or two at a time
+    in packed arithmetic."""
     case = CASES[name]
-    a, b = run_pair(case, tuning={"cells_per_thread": cells_per_thread})
+    a, b = run_pair(case, tuning={"cells_per_thread": cells_per_thread, "cells_together": cells_together})
     try:
         a.run(case["steps"]); b.run(case["steps"])
-        compare(a, b, "%s V=%d" % (name, cells_per_thread))
+        compare(a, b, "%s V=%d P=%d" % (name, cells_per_thread, cells_together))
     finally:
         a.close()
 
@@ -131,14 +133,15 @@ RAGGED = {
 }
 
 
+@pytest.mark.parametrize("cells_together", [0, 2])
 @pytest.mark.parametrize("name", sorted(RAGGED))
-def test_ragged_shapes_and_halos(gpu, name):
+def test_ragged_shapes_and_halos(gpu, name, cells_together):
     from tests import cases as CS
     from cfd_amd import setups
     case = RAGGED[name]
     setup = {"tgv": setups.taylor_green, "channel": CS._channel_setup, "all": CS._all_features_setup, "inflow": setups.inflow_box,
              "cavity": setups.lid_cavity, "tgv2d": CS._tgv2d}[case["setup"]]
-    a, b = run_pair(dict(kw=case["kw"], setup=setup))
+    a, b = run_pair(dict(kw=case["kw"], setup=setup), tuning={"cells_together": cells_together} if cells_together else None)
     try:
         a.run(1); b.run(1)
         compare(a, b, name + " t=1")
@@ -160,7 +163,7 @@ def test_geometry_search_is_invisible_in_the_results(gpu):
         assert a.get_tuning("autotune") == 1 and b.get_tuning("autotune") == 0
         a.run(60); b.run(60)
         assert a.get_tuning("tuned") == 1 and b.get_tuning("tuned") == 0
-        assert a.get_tuning("cells_per_thread") in (1, 2, 4) and 0 <= a.get_tuning("blocks_per_cu") <= 8
+        assert a.get_tuning("cells_per_thread") in (1, 2, 4) and a.get_tuning("cells_together") in (1, 2) and 0 <= a.get_tuning("blocks_per_cu") <= 8
         a.read_from_device(); b.read_from_device()
         assert np.array_equal(a.u.view(np.uint32), b.u.view(np.uint32)) and np.array_equal(a.rho.view(np.uint32), b.rho.view(np.uint32))
         assert np.array_equal(a.domains[0].download_fi(), b.domains[0].download_fi())

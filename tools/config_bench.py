@@ -15,6 +15,9 @@ F = L.FEATURES
 CONFIGS = {
     "cavity128_fp32_mb": dict(N=(128, 128, 128), Q=19, st="FP32", coll="SRT", feat=F["MOVING_BOUNDARIES"], walls=True),
     "tgv512_fp32": dict(N=(512, 512, 512), Q=19, st="FP32", coll="SRT", feat=0),
+    "tgv512_fp16s": dict(N=(512, 512, 512), Q=19, st="FP16S", coll="SRT", feat=0),
+    "tgv512_fp16c": dict(N=(512, 512, 512), Q=19, st="FP16C", coll="SRT", feat=0),
+    "q27_384_fp16c": dict(N=(384, 384, 384), Q=27, st="FP16C", coll="SRT", feat=0),
     "tgv512_fp32_trt": dict(N=(512, 512, 512), Q=19, st="FP32", coll="TRT", feat=0),
     "tgv512_fp32_sgs": dict(N=(512, 512, 512), Q=19, st="FP32", coll="SRT", feat=F["SUBGRID"]),
     "gui512_fp16s": dict(N=(512, 512, 512), Q=19, st="FP16S", coll="SRT", feat=F["UPDATE_FIELDS"] | F["VOLUME_FORCE"] | F["EQUILIBRIUM_BOUNDARIES"] | F["SUBGRID"], mask=True, f=(0.0, 0.0, 1e-5)),
@@ -71,18 +74,20 @@ def run(name, c):
 
         per, line = measure("default", warm=100)  # covers the library's geometry search
         got = {}
-        for key in ("tuned", "cells_per_thread", "blocks_per_cu", "block"):
+        for key in ("tuned", "cells_per_thread", "cells_together", "blocks_per_cu", "block"):
             v = C.c_int(); L.check(lib.lbmhip_get_tuning(dom.h, key.encode(), C.byref(v))); got[key] = v.value
-        print(line + "  [tuned=%(tuned)d V=%(cells_per_thread)d blocks/CU<=%(blocks_per_cu)d block=%(block)d]" % got, flush=True)
+        print(line + "  [tuned=%(tuned)d V=%(cells_per_thread)d P=%(cells_together)d blocks/CU<=%(blocks_per_cu)d block=%(block)d]" % got, flush=True)
         if SWEEP:
             res = []
             for b in BLOCKS:
-                for v in (1, 2, 4):
+                for v, p in ((1, 1), (2, 1), (4, 1), (2, 2), (4, 2)):
                     for k in (0, 2, 3, 4, 5, 6, 7, 8):
-                        for key, val in (("cells_per_thread", v), ("blocks_per_cu", k), ("block", b)):
+                        if p == 2 and k > 4:
+                            continue
+                        for key, val in (("cells_per_thread", v), ("cells_together", p), ("blocks_per_cu", k), ("block", b)):
                             L.check(lib.lbmhip_set_tuning(dom.h, key.encode(), val))
-                        res.append(measure("V=%d blocks/CU<=%d block=%d" % (v, k, b or 256)))
-            for per, line in sorted(res)[:6]:
+                        res.append(measure("V=%d P=%d blocks/CU<=%d block=%d" % (v, p, k, b or 256)))
+            for per, line in sorted(res)[:8]:
                 print("   " + line, flush=True)
     finally:
         dom.close()

@@ -35,18 +35,20 @@ def main():
             c["valu" if op.startswith("v_") else "salu" if op.startswith("s_") else "load" if "_load" in op else "store" if "_store" in op else "other"] += 1
             if op.startswith("s_cbranch"):
                 c["branch"] += 1
+            if op.startswith("v_pk_"):
+                c["packed"] += 1
         m = re.match(r"; (NumVgprs|Occupancy|ScratchSize): (\d+)", t)
         if m:
             stats[cur][m.group(1)] = int(m.group(2))
     for k, c in stats.items():
         m = re.match(r"_ZN3lbm9k_collideILi(\d+)ELi(\d+)ELi(\d+)ELi(n?\d+)ELb(\d)", k)
-        w = re.match(r"_ZN3lbm14k_collide_wideILi(\d+)ELi(\d+)ELi(\d+)ELi(n?\d+)ELi(\d+)E", k)
+        w = re.match(r"_ZN3lbm14k_collide_wideILi(\d+)ELi(\d+)ELi(\d+)ELi(n?\d+)ELi(\d+)ELi(\d+)E", k)
         if not (m or w) or c["valu"] < 50:
             continue
-        tag = "Q%s st%s coll%s feat%s V1 fields%s" % m.groups() if m else "Q%s st%s coll%s feat%s V%s wide" % w.groups()
+        tag = "Q%s st%s coll%s feat%s V1 fields%s" % m.groups() if m else "Q%s st%s coll%s feat%s V%s P%s wide" % w.groups()
         if flt in tag:
-            print("%-40s valu %4d salu %4d branch %3d load %3d store %3d vgpr %3d occ %d scratch %d" % (
-                tag, c["valu"], c["salu"], c["branch"], c["load"], c["store"], c["NumVgprs"], c["Occupancy"], c["ScratchSize"]))
+            print("%-44s valu %4d (packed %4d) salu %4d branch %3d load %3d store %3d vgpr %3d occ %d scratch %d" % (
+                tag, c["valu"], c["packed"], c["salu"], c["branch"], c["load"], c["store"], c["NumVgprs"], c["Occupancy"], c["ScratchSize"]))
 
 
 if __name__ == "__main__":
