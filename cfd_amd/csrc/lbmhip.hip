@@ -6,6 +6,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -291,7 +292,7 @@ int lbmhip_comm_join(lbmhip_domain* d) {
 int lbmhip_upload(lbmhip_domain* d, int field, const void* host, uint64_t offset, uint64_t bytes) {
 	NEED(d && host, "null argument");
 	NEED(field >= 0 && field < 5 && d->field[field], "field %d does not exist in this domain", field);
-	NEED(offset+bytes <= d->field_bytes[field], "upload of %llu bytes at offset %llu exceeds field %d (%llu bytes)",
+	NEED(bytes <= d->field_bytes[field] && offset <= d->field_bytes[field]-bytes, "upload of %llu bytes at offset %llu exceeds field %d (%llu bytes)",
 	     (unsigned long long)bytes, (unsigned long long)offset, field, (unsigned long long)d->field_bytes[field]);
 	DeviceGuard g(d->cfg.device);
 	HIP_TRY(hipMemcpyAsync((char*)d->field[field]+offset, host, bytes, hipMemcpyHostToDevice, d->stream));
@@ -301,7 +302,7 @@ int lbmhip_upload(lbmhip_domain* d, int field, const void* host, uint64_t offset
 int lbmhip_download(lbmhip_domain* d, int field, void* host, uint64_t offset, uint64_t bytes) {
 	NEED(d && host, "null argument");
 	NEED(field >= 0 && field < 5 && d->field[field], "field %d does not exist in this domain", field);
-	NEED(offset+bytes <= d->field_bytes[field], "download of %llu bytes at offset %llu exceeds field %d (%llu bytes)",
+	NEED(bytes <= d->field_bytes[field] && offset <= d->field_bytes[field]-bytes, "download of %llu bytes at offset %llu exceeds field %d (%llu bytes)",
 	     (unsigned long long)bytes, (unsigned long long)offset, field, (unsigned long long)d->field_bytes[field]);
 	DeviceGuard g(d->cfg.device);
 	HIP_TRY(hipMemcpyAsync(host, (const char*)d->field[field]+offset, bytes, hipMemcpyDeviceToHost, d->stream));

@@ -177,7 +177,16 @@ int main(int argc, char** argv) {
 	const unsigned n = argc > 1 ? atoi(argv[1]) : 512;
 	const size_t N = (size_t)n*n*n, padmax = 1u<<20;
 	const bool oop = argc > 2 && atoi(argv[2]) != 0; // second argument 1: streams are written to a second buffer (two-lattice pattern)
-	float* fi; CHECK(hipMalloc(&fi, (N+padmax)*19*sizeof(float)*(oop ? 2 : 1)));
+	float* fi;
+	{ // MB_ALLOC=uncached | finegrained | contiguous selects the memory type of the lattice (default: ordinary hipMalloc)
+		const char* kind = getenv("MB_ALLOC");
+		const size_t bytes = (N+padmax)*19*sizeof(float)*(oop ? 2 : 1);
+		if (kind && !strcmp(kind, "uncached")) CHECK(hipExtMallocWithFlags((void**)&fi, bytes, hipDeviceMallocUncached));
+		else if (kind && !strcmp(kind, "finegrained")) CHECK(hipExtMallocWithFlags((void**)&fi, bytes, hipDeviceMallocFinegrained));
+		else if (kind && !strcmp(kind, "contiguous")) CHECK(hipExtMallocWithFlags((void**)&fi, bytes, hipDeviceMallocContiguous));
+		else CHECK(hipMalloc(&fi, bytes));
+		printf("allocation: %s\n", kind ? kind : "default");
+	}
 	float* fo = oop ? fi+(N+padmax)*19 : fi;
 	CHECK(hipMemset(fi, 0, (N+padmax)*19*sizeof(float)));
 	{
