@@ -25,6 +25,13 @@ CONFIGS = {
     "fp16s_1024": dict(N=(1024, 1024, 1024), Q=19, st="FP16S", coll="SRT", feat=0),
     "fp16s_768": dict(N=(768, 768, 768), Q=19, st="FP16S", coll="SRT", feat=0),
     "fp16s_512x1600x512": dict(N=(512, 1600, 512), Q=19, st="FP16S", coll="SRT", feat=0),
+    "fp32_1024x512x512": dict(N=(1024, 512, 512), Q=19, st="FP32", coll="SRT", feat=0),
+    "fp32_512x1024x512": dict(N=(512, 1024, 512), Q=19, st="FP32", coll="SRT", feat=0),
+    "fp32_512x512x1024": dict(N=(512, 512, 1024), Q=19, st="FP32", coll="SRT", feat=0),
+    "fp32_768x512x512": dict(N=(768, 512, 512), Q=19, st="FP32", coll="SRT", feat=0),
+    "fp32_576x512x512": dict(N=(576, 512, 512), Q=19, st="FP32", coll="SRT", feat=0),
+    "fp32_512x520x512": dict(N=(512, 520, 512), Q=19, st="FP32", coll="SRT", feat=0),
+    "fp32_512x512x520": dict(N=(512, 512, 520), Q=19, st="FP32", coll="SRT", feat=0),
     "fp32_1024": dict(N=(1024, 1024, 1024), Q=19, st="FP32", coll="SRT", feat=0),
     "fp32_1600x512x512": dict(N=(1600, 512, 512), Q=19, st="FP32", coll="SRT", feat=0),
     "capacity1600_fp16s": dict(N=(1600, 1600, 1600), Q=19, st="FP16S", coll="SRT", feat=0),
