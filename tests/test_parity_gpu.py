@@ -129,6 +129,12 @@ RAGGED = {
     "fp32_260x6x6": dict(kw=dict(N=(260, 6, 6), nu=0.02), setup="tgv"),
     "fp16s_1028x4x4_wide": dict(kw=dict(N=(1028, 4, 4), nu=0.02, storage="FP16S"), setup="tgv"),
     "q15_fp16s_3dom": dict(kw=dict(N=(24, 24, 12), nu=0.02, Q=15, D=(1, 3, 1), storage="FP16S"), setup="tgv"),
+    # degenerate lattices: every neighbour of a cell is the cell itself, or the lattice is a line / a sheet
+    "fp32_1x1x1": dict(kw=dict(N=(1, 1, 1), nu=0.02), setup="tgv"),
+    "fp32_2x3x1_trt": dict(kw=dict(N=(2, 3, 1), nu=0.02, collision="TRT"), setup="tgv"),
+    "fp16s_64x1x1": dict(kw=dict(N=(64, 1, 1), nu=0.02, storage="FP16S"), setup="tgv"),
+    "fp16c_1x1x40_q27": dict(kw=dict(N=(1, 1, 40), nu=0.02, Q=27, storage="FP16C"), setup="tgv"),
+    "fp32_4x1x8_2dom": dict(kw=dict(N=(4, 1, 8), nu=0.02, D=(1, 1, 2), features=("VOLUME_FORCE",), f=(0.0, 0.0, 1e-4)), setup="tgv"),
     "q9_fp16c_4dom": dict(kw=dict(N=(40, 24, 1), nu=0.02, Q=9, D=(2, 2, 1), storage="FP16C"), setup="tgv2d"),
 }
 
