@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <string>
 #include <vector>
 
@@ -86,6 +87,29 @@ static Args make_args(const lbmhip_domain* d, uint64_t t, float fx, float fy, fl
 	a.tau0 = 1.0f/d->w; a.wm = 1.0f/(0.1875f/(1.0f/d->w-0.5f)+0.5f); // kernel.cpp:1598, 1624 (IEEE float division, as on the device)
 	return a;
 }
+
+// RCCL entry points, resolved at first use: from the running process (the caller's RCCL), else from librccl.so
+namespace {
+typedef int (*rccl_group_fn)(void);
+typedef int (*rccl_p2p_fn)(void*, size_t, int, int, void*, hipStream_t); // ncclSend / ncclRecv (the send buffer is const in RCCL's prototype)
+typedef const char* (*rccl_error_fn)(int);
+struct RcclApi { rccl_group_fn group_start, group_end; rccl_p2p_fn send, recv; rccl_error_fn error_string; bool ok; };
+const RcclApi& rccl_api() {
+	static const RcclApi api = []() {
+		RcclApi a = {};
+		void* h = RTLD_DEFAULT;
+		if (!dlsym(h, "ncclSend")) h = dlopen("librccl.so.1", RTLD_NOW|RTLD_GLOBAL);
+		if (!h) h = dlopen("librccl.so", RTLD_NOW|RTLD_GLOBAL);
+		if (!h) return a;
+		a.group_start = (rccl_group_fn)dlsym(h, "ncclGroupStart"); a.group_end = (rccl_group_fn)dlsym(h, "ncclGroupEnd");
+		a.send = (rccl_p2p_fn)dlsym(h, "ncclSend"); a.recv = (rccl_p2p_fn)dlsym(h, "ncclRecv");
+		a.error_string = (rccl_error_fn)dlsym(h, "ncclGetErrorString");
+		a.ok = a.group_start && a.group_end && a.send && a.recv;
+		return a;
+	}();
+	return api;
+}
+} // namespace
 
 extern "C" {
 
@@ -593,6 +617,20 @@ int lbmhip_halo_set_buffers(lbmhip_domain* d, void* send_p, void* send_m, void* 
 	return 0;
 }
 
+// Direct device-to-device copies over xGMI need peer access switched on once per ordered device pair; without it
+// hipMemcpyPeerAsync still works but stages through host memory.  Failure to enable it is therefore not an error.
+static void enable_peer_access(int device, int peer) {
+	static bool tried[64][64];
+	if (device == peer || device < 0 || peer < 0 || device >= 64 || peer >= 64 || tried[device][peer]) return;
+	tried[device][peer] = true;
+	DeviceGuard g(device);
+	int can = 0;
+	if (g.ok && hipDeviceCanAccessPeer(&can, device, peer) == hipSuccess && can) {
+		const hipError_t e = hipDeviceEnablePeerAccess(peer, 0);
+		if (e != hipSuccess) (void)hipGetLastError(); // already enabled, or not possible: copies fall back to staging
+	}
+}
+
 int lbmhip_halo_exchange_local(lbmhip_domain** doms, uint32_t count, int what, int axis) {
 	NEED(doms && count > 0u, "null argument");
 	const lbmhip_config& c0 = doms[0]->cfg;
@@ -610,6 +648,8 @@ int lbmhip_halo_exchange_local(lbmhip_domain** doms, uint32_t count, int what, i
 		pos[axis] = (pos[axis]+1u)%dd; // periodic wrap (lbm.cpp:2130-2132)
 		lbmhip_domain* d = doms[k];
 		lbmhip_domain* p = doms[pos[0]+(pos[1]+pos[2]*Dy)*Dx];
+		enable_peer_access(d->cfg.device, p->cfg.device);
+		enable_peer_access(p->cfg.device, d->cfg.device);
 		{ // d's + face -> p's - halo, on p's stream
 			DeviceGuard g(p->cfg.device);
 			HIP_TRY(hipStreamWaitEvent(p->stream, d->ev_packed, 0));
@@ -627,6 +667,28 @@ int lbmhip_halo_exchange_local(lbmhip_domain** doms, uint32_t count, int what, i
 		DeviceGuard g(doms[k]->cfg.device);
 		for (uint32_t q = 0; q < count; q++) if (q != k) HIP_TRY(hipStreamWaitEvent(doms[k]->stream, doms[q]->ev_copied, 0));
 	}
+	return 0;
+}
+
+int lbmhip_halo_exchange_rccl(lbmhip_domain* d, void* comm, int what, int axis, int rank_minus, int rank_plus) {
+	if (halo_check(d, what, axis)) return 1;
+	NEED(comm, "null communicator");
+	NEED(rank_minus >= 0 && rank_plus >= 0, "neighbour ranks must not be negative");
+	const RcclApi& api = rccl_api();
+	NEED(api.ok, "RCCL is not loaded in this process and librccl.so could not be opened");
+	const size_t bytes = (size_t)(face_area(d, axis)*halo_bytes_per_cell(d, what));
+	NEED(bytes <= d->halo_capacity, "staging buffers too small (%llu bytes)", (unsigned long long)d->halo_capacity);
+	DeviceGuard g(d->cfg.device);
+	const int kUint8 = 1; // ncclUint8
+	// with a single peer on both sides the two messages are matched in the order they are issued: + face first on both ends
+	int e = api.group_start();
+	if (e == 0) e = api.send(d->halo[LBMHIP_BUF_SEND_P], bytes, kUint8, rank_plus, comm, d->stream);
+	if (e == 0) e = api.send(d->halo[LBMHIP_BUF_SEND_M], bytes, kUint8, rank_minus, comm, d->stream);
+	if (e == 0) e = api.recv(d->halo[LBMHIP_BUF_RECV_M], bytes, kUint8, rank_minus, comm, d->stream);
+	if (e == 0) e = api.recv(d->halo[LBMHIP_BUF_RECV_P], bytes, kUint8, rank_plus, comm, d->stream);
+	const int e_end = api.group_end(); // always close the group
+	if (e == 0) e = e_end;
+	if (e != 0) return fail("RCCL send/recv failed: %s", api.error_string ? api.error_string(e) : "unknown error");
 	return 0;
 }
 

@@ -126,6 +126,12 @@ int lbmhip_halo_set_buffers(lbmhip_domain* domain, void* send_p, void* send_m, v
  * device (peer copies over xGMI when the domains sit on different GPUs), with periodic wrap.  domains[] is
  * ordered d = x+(y+z*Dy)*Dx.  Orders the copies after each domain's pack and before its unpack. */
 int lbmhip_halo_exchange_local(lbmhip_domain** domains, uint32_t count, int what, int axis);
+/* the same exchange (lbm.cpp:2129-2136) for ONE PROCESS PER GPU: sends SEND_P to rank_plus and SEND_M to rank_minus and
+ * receives RECV_M from rank_minus and RECV_P from rank_plus, as one RCCL send/recv group on the handle's stream (ordered
+ * after pack, before unpack; nothing blocks the host).  communicator is the caller's ncclComm_t for this GPU; the RCCL
+ * entry points are looked up in the process at the first call (the caller that created the communicator has them loaded),
+ * so the library itself does not link RCCL.  rank_minus == rank_plus (two ranks, or one rank that is its own neighbour) works. */
+int lbmhip_halo_exchange_rccl(lbmhip_domain* domain, void* communicator, int what, int axis, int rank_minus, int rank_plus);
 
 /* ---- mesh voxelizer: LBM_Domain::voxelize_mesh_on_device / enqueue_unvoxelize_mesh_on_device (lbm.cpp:344-422) and the
  * kernels voxelize_mesh / unvoxelize_mesh (kernel.cpp:2295-2390).  p0, p1, p2: HOST arrays of 3*triangles floats (the three

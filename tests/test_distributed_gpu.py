@@ -153,3 +153,59 @@ def test_capacity_lattice_1600_fp16s(gpu):
     ref.read_from_device()
     assert np.abs(got).max() > 1e-3
     assert np.array_equal(got.view(np.uint32), ref.u.view(np.uint32)), "n=%d" % n
+
+
+def _rccl_abi_worker(_index, kw, steps, overlap, out_dir):
+    """One rank whose slab is its own z-neighbour, halos exchanged by lbmhip_halo_exchange_rccl on a communicator made
+    with RCCL's C API (no torch.distributed anywhere)."""
+    sys.path.insert(0, ROOT)
+    import torch
+    torch.cuda.set_device(0)
+    import cfd_amd
+    from cfd_amd import setups
+    from cfd_amd import distributed as DD
+    from cfd_amd.lbm import check
+    rccl = C.CDLL("librccl.so.1", mode=C.RTLD_GLOBAL)
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    uid, comm = UniqueId(), C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    lib = cfd_amd.lib()
+    kw = dict(kw)
+    N = kw.pop("N")
+    lbm = DD.DistributedLBM((N[0], N[1], 2 * N[2]), rank=0, world=2, overlap=overlap, **kw)
+
+    def communicate(what):
+        lbm.ops.pack(what, lbm.t)
+        check(lib.lbmhip_halo_exchange_rccl(lbm.ops.dom.h, comm, DD.WHAT[what], 2, 0, 0))
+        lbm.ops.unpack(what, lbm.t)
+    lbm._communicate = communicate
+    with cfd_amd.LBM(N, **kw) as single:
+        setups.channel(single)
+        lbm.rho[...] = single.rho; lbm.u[...] = single.u; lbm.flags[...] = single.flags
+        single.run(steps)
+        single.read_from_device()
+        lbm.run(steps)
+        lbm.read_from_device()
+        np.savez(os.path.join(out_dir, "abi.npz"), rho=lbm.rho, u=lbm.u, flags=lbm.flags, rho0=single.rho, u0=single.u, flags0=single.flags)
+    # misuse is reported, not executed
+    assert lib.lbmhip_halo_exchange_rccl(lbm.ops.dom.h, None, DD.WHAT["fi"], 2, 0, 0) != 0
+    assert lib.lbmhip_halo_exchange_rccl(lbm.ops.dom.h, comm, DD.WHAT["fi"], 0, 0, 0) != 0  # x has a single domain
+    lbm.ops.sync()
+    lbm.close()
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    rccl.ncclCommDestroy(comm)
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_rccl_entry_point_of_the_abi(gpu, tmp_path, overlap):
+    kw = dict(N=(64, 32, 24), nu=0.01, Q=27, storage="FP16C", collision="SRT", features=("VOLUME_FORCE",), f=(1e-4, 0.0, 0.0))
+    mp.spawn(_rccl_abi_worker, args=(kw, 20, overlap, str(tmp_path)), nprocs=1, join=True)
+    got = np.load(os.path.join(str(tmp_path), "abi.npz"))
+    assert np.array_equal(got["flags"], got["flags0"])
+    assert np.array_equal(got["rho"].view(np.uint32), got["rho0"].view(np.uint32))
+    assert np.array_equal(got["u"].view(np.uint32), got["u0"].view(np.uint32))
+    assert float(np.abs(got["u"]).max()) > 1e-4
