@@ -20,6 +20,7 @@ static int fail(const char* fmt, ...) {
 	char buf[1024];
 	va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
 	g_error = buf;
+	(void)hipGetLastError(); // HIP keeps the last error until it is read: a reported failure must not resurface in a later call's launch check
 	return 1;
 }
 #define HIP_TRY(expr) do { const hipError_t e_ = (expr); if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
@@ -71,7 +72,7 @@ static bool valid_q(uint32_t Q) { return Q == 9u || Q == 15u || Q == 19u || Q ==
 
 struct DeviceGuard { // makes the domain's device current for the duration of a call
 	int prev; bool ok;
-	explicit DeviceGuard(int dev) : prev(0), ok(true) { if (hipGetDevice(&prev) != hipSuccess || (prev != dev && hipSetDevice(dev) != hipSuccess)) ok = false; }
+	explicit DeviceGuard(int dev) : prev(0), ok(true) { (void)hipGetLastError(); /* drop a stale error left by other code in the process */ if (hipGetDevice(&prev) != hipSuccess || (prev != dev && hipSetDevice(dev) != hipSuccess)) ok = false; }
 	~DeviceGuard() { int cur = 0; if (hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev); }
 };
 
