@@ -200,3 +200,25 @@ def test_keys_reach_a_running_setup_through_stdin_and_signals(gpu, tmp_path):
     finally:
         if p.poll() is None:
             p.kill()
+
+
+@pytest.mark.parametrize("case,message", [
+    (1, "Viscosity cannot be 0"),
+    (2, "Viscosity cannot be negative"),
+    (3, "VOLUME_FORCE is not enabled"),
+    (4, "EQUILIBRIUM_BOUNDARIES is not enabled"),
+    (5, "Grid point number is 0"),
+    (6, "does not exist"),
+    (7, "0 LBM grid domains"),
+])
+def test_misconfigured_setups_end_like_the_reference(gpu, case, message):
+    """print_error of the reference: one '| Error:' line and exit status 1 (FluidX3D-master/src/utilities.hpp:4159-4166);
+    the messages are those of lbm.cpp:1038-1124 and of the sanity checks before initialize."""
+    exe = os.path.join(BIN, "error_cases")
+    assert os.path.exists(exe), exe + " is missing: make -C cfd_amd/host"
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120, env=dict(os.environ, LBM_ERROR_CASE=str(case)))
+    assert r.returncode == 1, r.stdout
+    assert "| Error: " in r.stdout and message in r.stdout, r.stdout
+    good = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120, env=dict(os.environ, LBM_ERROR_CASE="0")) if case == 1 else None
+    if good is not None:
+        assert good.returncode == 0 and "ran 1 step" in good.stdout, good.stdout
