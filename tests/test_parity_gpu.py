@@ -173,3 +173,24 @@ def test_geometry_search_is_invisible_in_the_results(gpu):
         a.read_from_device(); b.read_from_device()
         assert np.array_equal(a.u.view(np.uint32), b.u.view(np.uint32)) and np.array_equal(a.rho.view(np.uint32), b.rho.view(np.uint32))
         assert np.array_equal(a.domains[0].download_fi(), b.domains[0].download_fi())
+
+
+def test_reset_restarts_from_the_host_fields(gpu):
+    """LBM::reset (FluidX3D-master/src/lbm.cpp:1498-1500): the next run() initializes again from the host copies of
+    rho, u and flags, with the step counter back at 0 - same as a fresh lattice holding those fields."""
+    from cfd_amd import setups
+    kw = dict(N=(24, 20, 16), nu=0.03, storage="FP16S", collision="TRT")
+    with cfd_amd.LBM(**kw) as a, cfd_amd.LBM(**kw) as fresh:
+        setups.taylor_green(a)
+        a.run(7)                      # odd step count: the parity of t must start over
+        a.read_from_device()
+        a.u[0] += 0.01
+        a.flags[3, 4, 5] = 1
+        fresh.rho[...] = a.rho; fresh.u[...] = a.u; fresh.flags[...] = a.flags
+        a.reset()
+        a.run(5); fresh.run(5)
+        assert a.t == 5
+        a.read_from_device(); fresh.read_from_device()
+        assert np.array_equal(a.u.view(np.uint32), fresh.u.view(np.uint32)) and np.array_equal(a.rho.view(np.uint32), fresh.rho.view(np.uint32))
+        assert np.array_equal(a.flags, fresh.flags)
+        assert np.array_equal(a.domains[0].download_fi(), fresh.domains[0].download_fi())
