@@ -3,7 +3,7 @@
 
   python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
 
-Workload (BASELINE.json configs[1]): periodic Taylor-Green vortex, D3Q19 SRT, FP32 DDFs, 512^3 cells per GPU,
+Workload (the configuration the headline metric is quoted on): periodic Taylor-Green vortex, D3Q19 SRT, FP32 DDFs, 512^3 cells per GPU,
 no UPDATE_FIELDS (153 algorithmic bytes per cell and step).  With N GPUs the lattice is 512 x 512 x (512 N), split
 into N z-slabs (weak scaling); the only communication is the per-step DDF halo exchange with the two z-neighbours.
 A step = one stream_collide pass over the whole lattice (+ halo exchange).  Inputs are resident in HBM before the
