@@ -222,3 +222,11 @@ def test_misconfigured_setups_end_like_the_reference(gpu, case, message):
     good = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120, env=dict(os.environ, LBM_ERROR_CASE="0")) if case == 1 else None
     if good is not None:
         assert good.returncode == 0 and "ran 1 step" in good.stdout, good.stdout
+
+
+@pytest.mark.parametrize("storage", ["FP32", "FP16S"])
+def test_cpp_slab_runner_over_rccl(gpu, storage):
+    """cfd_amd/host/slab_rccl.cpp: one process per GPU in C++ (C ABI + RCCL, no Python in the loop).  With one rank that is
+    its own z-neighbour the overlapped exchange must reproduce the periodic lattice bit for bit."""
+    out = run_example("slab_rccl", timeout=200, env=dict(LBM_SLAB_SELF="1", LBM_SLAB_N="128", LBM_SLAB_STEPS="60", LBM_SLAB_STORAGE=storage))
+    assert "halo exchange over RCCL, overlapped" in out and "bit-identical" in out, out
