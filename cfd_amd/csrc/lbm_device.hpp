@@ -23,6 +23,7 @@ enum : uint8_t { TYPE_S = 0x01, TYPE_E = 0x02, TYPE_MS = 0x03, TYPE_BO = 0x03, T
 struct Args {
 	void* fi; float* rho; float* u; uint8_t* flags; float* F;
 	uint64_t N;          // cells in the local lattice
+	uint64_t S;          // distance between two DDF streams in elements (>= N)
 	uint32_t Nx, Ny, Nz; // local lattice (with halo)
 	uint32_t hx, hy, hz; // 1 where the axis has a halo layer on both ends
 	uint32_t z0, z1;     // planes handled by this launch

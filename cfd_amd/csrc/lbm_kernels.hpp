@@ -59,8 +59,8 @@ __global__ __launch_bounds__(256) void k_collide(const Args a) {
 	static_for<1, Q, 2>([&](auto I) {
 		constexpr int i = I, cx = dir<Q>(i,0), cy = dir<Q>(i,1), cz = dir<Q>(i,2);
 		const uint32_t sA = a.odd ? i : i+1, sB = a.odd ? i+1 : i;
-		f[i] = S::decode(fi[(uint64_t)sA*a.N+n]);
-		const raw* pn = fi+(uint64_t)sB*a.N+((uint64_t)zq[cz == 0 ? 0 : cz > 0 ? 1 : 2]*a.Ny+yq[cy == 0 ? 0 : cy > 0 ? 1 : 2])*a.Nx;
+		f[i] = S::decode(fi[(uint64_t)sA*a.S+n]);
+		const raw* pn = fi+(uint64_t)sB*a.S+((uint64_t)zq[cz == 0 ? 0 : cz > 0 ? 1 : 2]*a.Ny+yq[cy == 0 ? 0 : cy > 0 ? 1 : 2])*a.Nx;
 		f[i+1] = S::decode(pn[cx == 0 ? x : cx > 0 ? xp : xm]);
 	});
 
@@ -79,8 +79,8 @@ __global__ __launch_bounds__(256) void k_collide(const Args a) {
 	static_for<1, Q, 2>([&](auto I) {
 		constexpr int i = I, cx = dir<Q>(i,0), cy = dir<Q>(i,1), cz = dir<Q>(i,2);
 		const uint32_t sA = a.odd ? i : i+1, sB = a.odd ? i+1 : i;
-		fi[(uint64_t)sA*a.N+n] = S::encode(f[i+1]);
-		raw* pn = fi+(uint64_t)sB*a.N+((uint64_t)zq[cz == 0 ? 0 : cz > 0 ? 1 : 2]*a.Ny+yq[cy == 0 ? 0 : cy > 0 ? 1 : 2])*a.Nx;
+		fi[(uint64_t)sA*a.S+n] = S::encode(f[i+1]);
+		raw* pn = fi+(uint64_t)sB*a.S+((uint64_t)zq[cz == 0 ? 0 : cz > 0 ? 1 : 2]*a.Ny+yq[cy == 0 ? 0 : cy > 0 ? 1 : 2])*a.Nx;
 		pn[cx == 0 ? x : cx > 0 ? xp : xm] = S::encode(f[i]);
 	});
 }
@@ -158,8 +158,8 @@ __global__ __launch_bounds__(256) void k_collide_wide(const Args a) {
 		static_for<1, Q, 2>([&](auto I) {
 			constexpr int i = I, cx = dir<Q>(i,0), cy = dir<Q>(i,1), cz = dir<Q>(i,2);
 			const uint32_t sA = a.odd ? i : i+1, sB = a.odd ? i+1 : i;
-			d[i] = *reinterpret_cast<const rvec*>(fi+(uint64_t)sA*a.N+row0+x);
-			const raw* pn = fi+(uint64_t)sB*a.N+((uint64_t)zq[cz == 0 ? 0 : cz > 0 ? 1 : 2]*a.Ny+yq[cy == 0 ? 0 : cy > 0 ? 1 : 2])*a.Nx;
+			d[i] = *reinterpret_cast<const rvec*>(fi+(uint64_t)sA*a.S+row0+x);
+			const raw* pn = fi+(uint64_t)sB*a.S+((uint64_t)zq[cz == 0 ? 0 : cz > 0 ? 1 : 2]*a.Ny+yq[cy == 0 ? 0 : cy > 0 ? 1 : 2])*a.Nx;
 			d[i+1] = *reinterpret_cast<const rvec*>(pn+x); // cells x..x+3 of the neighbour row; shifted below when cx != 0
 			if constexpr (cx > 0) { if (seam_hi) seam[i+1] = pn[x_hi]; }
 			if constexpr (cx < 0) { if (seam_lo) seam[i+1] = pn[x_lo]; }
@@ -286,8 +286,8 @@ __global__ __launch_bounds__(256) void k_collide_wide(const Args a) {
 	static_for<1, Q, 2>([&](auto I) {
 		constexpr int i = I, cx = dir<Q>(i,0), cy = dir<Q>(i,1), cz = dir<Q>(i,2);
 		const uint32_t sA = a.odd ? i : i+1, sB = a.odd ? i+1 : i;
-		*reinterpret_cast<rvec*>(fi+(uint64_t)sA*a.N+row0+x) = d[i];
-		raw* pn = fi+(uint64_t)sB*a.N+((uint64_t)zq[cz == 0 ? 0 : cz > 0 ? 1 : 2]*a.Ny+yq[cy == 0 ? 0 : cy > 0 ? 1 : 2])*a.Nx;
+		*reinterpret_cast<rvec*>(fi+(uint64_t)sA*a.S+row0+x) = d[i];
+		raw* pn = fi+(uint64_t)sB*a.S+((uint64_t)zq[cz == 0 ? 0 : cz > 0 ? 1 : 2]*a.Ny+yq[cy == 0 ? 0 : cy > 0 ? 1 : 2])*a.Nx;
 		if constexpr (cx == 0) *reinterpret_cast<rvec*>(pn+x) = d[i+1];
 		else if constexpr (cx > 0) { // d[i+1] holds cells x+1..x+V
 			if (!seam_lo) {
@@ -347,8 +347,8 @@ template <int Q, int ST> __device__ __forceinline__ void load_f(const Args& a, u
 	f[0] = S::decode(fi[n]);
 	static_for<1, Q, 2>([&](auto I) {
 		constexpr int i = I;
-		f[i]   = S::decode(fi[(uint64_t)(odd ? i : i+1)*a.N+n]);
-		f[i+1] = S::decode(fi[(uint64_t)(odd ? i+1 : i)*a.N+j[i]]);
+		f[i]   = S::decode(fi[(uint64_t)(odd ? i : i+1)*a.S+n]);
+		f[i+1] = S::decode(fi[(uint64_t)(odd ? i+1 : i)*a.S+j[i]]);
 	});
 }
 
@@ -381,8 +381,8 @@ template <int Q, int ST> __global__ __launch_bounds__(256) void k_initialize(con
 	fi[n] = S::encode(feq[0]);
 	static_for<1, Q, 2>([&](auto I) {
 		constexpr int i = I;
-		fi[(uint64_t)(i+1)*a.N+j[i]] = S::encode(feq[i]);
-		fi[(uint64_t)i*a.N+n] = S::encode(feq[i+1]);
+		fi[(uint64_t)(i+1)*a.S+j[i]] = S::encode(feq[i]);
+		fi[(uint64_t)i*a.S+n] = S::encode(feq[i+1]);
 	});
 }
 
@@ -456,8 +456,8 @@ template <int Q, int ST> __global__ __launch_bounds__(256) void k_halo_fi(const 
 					const uint64_t k = (uint64_t)b*h.A+fa;
 					auto move = [&](auto II) {
 						constexpr int i = II, opp = (i%2) ? i+1 : i-1;
-						if (!h.insert) buf[k] = fi[(uint64_t)(a.odd ? opp : i)*a.N+((i%2) ? j[i] : n)];                 // kernel.cpp:2135
-						else fi[(uint64_t)(a.odd ? i : opp)*a.N+((i%2) ? n : j[(i%2) ? i : i-1])] = buf[k];            // kernel.cpp:2144
+						if (!h.insert) buf[k] = fi[(uint64_t)(a.odd ? opp : i)*a.S+((i%2) ? j[i] : n)];                 // kernel.cpp:2135
+						else fi[(uint64_t)(a.odd ? i : opp)*a.S+((i%2) ? n : j[(i%2) ? i : i-1])] = buf[k];            // kernel.cpp:2144
 					};
 					if (side == 0u) move(std::integral_constant<int, P>{}); else move(std::integral_constant<int, M>{});
 				});
@@ -579,8 +579,8 @@ template <int Q, int ST> __global__ __launch_bounds__(64) void k_voxelize_mesh(c
 					fi[n] = S::encode(feq[0]);
 					static_for<1, Q, 2>([&](auto I) {
 						constexpr int i = I;
-						fi[(uint64_t)(a.odd ? i+1 : i)*a.N+j[i]] = S::encode(feq[i]);
-						fi[(uint64_t)(a.odd ? i : i+1)*a.N+n] = S::encode(feq[i+1]);
+						fi[(uint64_t)(a.odd ? i+1 : i)*a.S+j[i]] = S::encode(feq[i]);
+						fi[(uint64_t)(a.odd ? i : i+1)*a.S+n] = S::encode(feq[i+1]);
 					});
 				}
 				fl = (fl&TYPE_BO) == TYPE_MS ? (uint8_t)(fl&~TYPE_MS) : (uint8_t)(fl&~v.flag);

@@ -3,6 +3,8 @@
 Bar: flags bit-exact; FP32 runs bit-exact in fi, rho and u (both sides evaluate the same FP32 operation order
 with fma only where the reference writes fma); FP16S/FP16C runs compare the raw 16-bit DDFs bit-exactly as well.
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -194,3 +196,38 @@ def test_reset_restarts_from_the_host_fields(gpu):
         assert np.array_equal(a.u.view(np.uint32), fresh.u.view(np.uint32)) and np.array_equal(a.rho.view(np.uint32), fresh.rho.view(np.uint32))
         assert np.array_equal(a.flags, fresh.flags)
         assert np.array_equal(a.domains[0].download_fi(), fresh.domains[0].download_fi())
+
+
+@pytest.mark.parametrize("pad", [4160, 131072])
+@pytest.mark.parametrize("name", ["all_fp16s_trt_2dom", "all_fp32_srt_8dom", "q27_fp16c_force", "cavity32_fp32_srt", "q27_fp32_trt_4slab"])
+def test_padded_stream_stride_is_invisible(gpu, monkeypatch, name, pad):
+    """Large domains with halo layers keep their DDF streams a padded stride apart (HBM channel spread); uploads,
+    downloads, halo kernels and every lattice kernel must address the streams through that stride.  LBMHIP_PAD forces a
+    padding on these small lattices; results and the downloaded DDFs (host layout: streams back to back) stay bit-exact."""
+    monkeypatch.setenv("LBMHIP_PAD", str(pad))
+    case = CASES[name]
+    a, b = run_pair(case)
+    try:
+        stride = C.c_uint64()
+        assert cfd_amd.lib().lbmhip_ddf_stride(a.domains[0].h, C.byref(stride)) == 0 and stride.value == a.domains[0].N + pad
+        a.run(case["steps"]); b.run(case["steps"])
+        compare(a, b, "%s pad=%d" % (name, pad))
+    finally:
+        a.close()
+
+
+def test_stream_stride_default_choice(gpu, monkeypatch):
+    monkeypatch.delenv("LBMHIP_PAD", raising=False)
+    lib = cfd_amd.lib()
+    from cfd_amd import lbm as L
+    # halo + large + stride not a multiple of 64 MiB -> 2^17 elements; everything else unpadded
+    for dims, D, want_pad in (((64, 64, 64), (1, 1, 2), 0), ((256, 256, 66), (1, 1, 2), 1 << 17), ((256, 256, 256), (1, 1, 2), 0), ((256, 256, 66), (1, 1, 1), 0)):
+        cfg = L.Config(dims[0], dims[1], dims[2], D[0], D[1], D[2], 0, 0, 0, 19, 0, 0, 0, 0.05, 0)
+        dom = L.Domain(cfg)
+        try:
+            stride = C.c_uint64()
+            assert lib.lbmhip_ddf_stride(dom.h, C.byref(stride)) == 0
+            n = dims[0] * dims[1] * dims[2]
+            assert stride.value - n == want_pad, (dims, D, stride.value - n)
+        finally:
+            dom.close()
