@@ -67,15 +67,16 @@ static hipError_t fill_words(void* p, uint32_t word, uint64_t count, hipStream_t
 }
 
 // Distance between two DDF streams.  The streams of a lattice are read and written side by side, so the stride decides how
-// the 2*Q concurrent streams fall onto the HBM channels.  Measured on MI355X: a stride that is a multiple of 64 MiB (512^3:
-// 512 MiB) is as good as it gets and is left alone; a domain with halo layers has a stride like 514 MiB, which costs 2-4 %
-// of the rate, and 2^17 elements of padding per stream win that back (34 070 -> 35 350 MLUPs/s at 512x512x514 FP32,
-// 70 000 -> 71 460 FP16S).  Padding is therefore added to domains with halo layers only, and only to lattices large enough
-// for it to matter.  LBMHIP_PAD=<elements> overrides the choice for every domain created afterwards (diagnostic, tests).
+// the 2*Q concurrent streams fall onto the HBM channels.  Measured on MI355X (512 x 512 x Nz lattices): a stride that is a
+// multiple of 64 MiB (512^3: 512 MiB; also 576, 768 MiB) is as good as it gets and padding it costs up to 2 %; any other
+// stride is 1-4 % slower than that, worst for a slab with two halo planes (514 MiB), and 2^17 elements of padding per
+// stream win it back (512x512x514 FP32: 34 070 -> 35 350 MLUPs/s, FP16S 70 000 -> 71 460; 600 planes: +2.2 %).  Streams
+// shorter than 64 MiB (not measured) stay unpadded.  LBMHIP_PAD=<elements> overrides the choice for every domain created
+// afterwards (diagnostic, tests).
 static uint64_t ddf_stream_padding(const lbmhip_config* c, uint64_t N, uint32_t fpxx_bytes) {
 	if (const char* pad = getenv("LBMHIP_PAD")) return (uint64_t)strtoull(pad, nullptr, 10);
-	const bool halo = c->Dx > 1u || c->Dy > 1u || c->Dz > 1u;
-	if (!halo || N < (1ull<<21) || (N*fpxx_bytes)%(64ull<<20) == 0ull) return 0ull;
+	(void)c;
+	if (N*fpxx_bytes < (64ull<<20) || (N*fpxx_bytes)%(64ull<<20) == 0ull) return 0ull;
 	return 1ull<<17;
 }
 

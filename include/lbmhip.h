@@ -100,8 +100,8 @@ int lbmhip_download(lbmhip_domain* domain, int field, void* host, uint64_t offse
 /* device address and size of a field, for callers that keep data resident (no copy) */
 int lbmhip_field_pointer(lbmhip_domain* domain, int field, void** device_pointer, uint64_t* bytes);
 /* Device layout of LBMHIP_FIELD_FI: stream i of the DDFs starts i*stride elements after the pointer above (element = 4 or
- * 2 bytes by storage).  stride >= Nx*Ny*Nz: domains with halo layers get a few hundred KiB of padding between the streams,
- * because an unpadded stride costs them 2-4 % of the step rate on MI355X.  lbmhip_upload / lbmhip_download hide this: they
+ * 2 bytes by storage).  stride >= Nx*Ny*Nz: lattices whose streams are longer than 64 MiB and would not start a multiple of 64 MiB apart (e.g. a slab with
+ * halo planes) get 2^17 elements of padding between the streams, because such strides cost 1-4 % of the step rate on MI355X.  lbmhip_upload / lbmhip_download hide this: they
  * address the DDFs as Q streams of Nx*Ny*Nz elements back to back, the layout of the reference (kernel.cpp:871-873). */
 int lbmhip_ddf_stride(const lbmhip_domain* domain, uint64_t* elements);
 

@@ -220,8 +220,8 @@ def test_stream_stride_default_choice(gpu, monkeypatch):
     monkeypatch.delenv("LBMHIP_PAD", raising=False)
     lib = cfd_amd.lib()
     from cfd_amd import lbm as L
-    # halo + large + stride not a multiple of 64 MiB -> 2^17 elements; everything else unpadded
-    for dims, D, want_pad in (((64, 64, 64), (1, 1, 2), 0), ((256, 256, 66), (1, 1, 2), 1 << 17), ((256, 256, 256), (1, 1, 2), 0), ((256, 256, 66), (1, 1, 1), 0)):
+    # streams of at least 64 MiB that are not a multiple of 64 MiB -> 2^17 elements; everything else unpadded
+    for dims, D, want_pad in (((64, 64, 64), (1, 1, 2), 0), ((512, 512, 66), (1, 1, 2), 1 << 17), ((512, 512, 64), (1, 1, 2), 0), ((512, 512, 66), (1, 1, 1), 1 << 17), ((256, 256, 66), (1, 1, 1), 0)):
         cfg = L.Config(dims[0], dims[1], dims[2], D[0], D[1], D[2], 0, 0, 0, 19, 0, 0, 0, 0.05, 0)
         dom = L.Domain(cfg)
         try:
