@@ -7,13 +7,13 @@ backend is "nccl", which is RCCL on ROCm).  There is no collective on the data p
 exchanges with at most two peers per rank; the periodic wrap connects the last rank with rank 0.
 
 Per time step (overlapped order):
-  1. stream_collide on the two lattice planes next to the halos           (compute stream)
-  2. pack -> send/recv -> unpack                                          (communication stream)
-  3. stream_collide on all other planes, concurrently with 2              (compute stream)
+  1. the communication stream waits for the previous step
+  2. stream_collide on the two lattice planes next to the halos, pack -> send/recv -> unpack   (communication stream)
+  3. stream_collide on all other planes, concurrently with 2                                   (compute stream)
   4. the compute stream waits for 2
-Every DDF slot is read and written by exactly one cell per step, and the slots that pack reads / unpack writes
-belong to cells of the two boundary planes (pack) or are only read by them in the NEXT step (unpack), so 2 and 3
-never touch the same memory.
+Every DDF slot is read and written by exactly one cell per step, so the two boundary planes may collide while the
+interior does; the slots that pack reads / unpack writes belong to cells of the two boundary planes (pack) or are only
+read by them in the NEXT step (unpack), so 2 and 3 never touch the same memory.
 
 The slab engine is abstract (SlabOps) so that the exchange logic can be driven by CPU tensors in tests; the
 product implementation is HipSlabOps (HIP kernels through the C ABI, staging buffers owned by torch).
@@ -258,10 +258,10 @@ class DistributedLBM:
         if self.world <= 1:
             o.collide_planes(self.t, self.f, 0, Lz)
         elif self.overlap:
-            o.collide_planes(self.t, self.f, 1, 2)
-            o.collide_planes(self.t, self.f, Lz - 2, Lz - 1)
             o.fork()
             try:
+                o.collide_planes(self.t, self.f, 1, 2)
+                o.collide_planes(self.t, self.f, Lz - 2, Lz - 1)
                 self._communicate("fi")
             finally:
                 o.end_fork()

@@ -39,10 +39,10 @@ struct Slab {
 	}
 	void step() {
 		if (!split) { check(lbmhip_stream_collide(dom, t, 0.0f, 0.0f, 0.0f)); t++; return; }
-		check(lbmhip_stream_collide_planes(dom, t, 0.0f, 0.0f, 0.0f, 1u, 2u));       // the two planes whose DDFs leave the slab
+		check(lbmhip_comm_begin(dom));                                                // on the second stream, after the previous step:
+		check(lbmhip_stream_collide_planes(dom, t, 0.0f, 0.0f, 0.0f, 1u, 2u));       // the two planes whose DDFs leave the slab,
 		check(lbmhip_stream_collide_planes(dom, t, 0.0f, 0.0f, 0.0f, Lz-2u, Lz-1u));
-		check(lbmhip_comm_begin(dom));                                                // halo traffic on the second stream ...
-		communicate(LBMHIP_HALO_FI);
+		communicate(LBMHIP_HALO_FI);                                                  // their exchange ...
 		check(lbmhip_comm_end(dom));
 		check(lbmhip_stream_collide_planes(dom, t, 0.0f, 0.0f, 0.0f, 2u, Lz-2u));   // ... while the interior collides
 		check(lbmhip_comm_join(dom));
