@@ -232,9 +232,14 @@ __global__ __launch_bounds__(256) void k_collide_wide(const Args a) {
 				float2v rhon, uxn, uyn, uzn;
 				collide<Q, COLL, false>(f, feat, bo, a, n, rhon, uxn, uyn, uzn, &wf[v]);
 				wf[v] = wf[v] && active[v]; wf[v+1] = wf[v+1] && active[v+1];
-				if (feat(F_UPDATE_FIELDS)) {
-					out[0][v] = rhon.x; out[1][v] = uxn.x; out[2][v] = uyn.x; out[3][v] = uzn.x;
-					out[0][v+1] = rhon.y; out[1][v+1] = uxn.y; out[2][v+1] = uyn.y; out[3][v+1] = uzn.y;
+				if (feat(F_UPDATE_FIELDS)) { // kernel.cpp:1581-1591; written pair by pair, which keeps four vectors of registers free
+					if (wf[v] && wf[v+1]) {
+						*reinterpret_cast<float2v*>(a.rho+n) = rhon; *reinterpret_cast<float2v*>(a.u+n) = uxn;
+						*reinterpret_cast<float2v*>(a.u+a.N+n) = uyn; *reinterpret_cast<float2v*>(a.u+2ull*a.N+n) = uzn;
+					} else {
+						if (wf[v]) { a.rho[n] = rhon.x; a.u[n] = uxn.x; a.u[a.N+n] = uyn.x; a.u[2ull*a.N+n] = uzn.x; }
+						if (wf[v+1]) { a.rho[n+1ull] = rhon.y; a.u[n+1ull] = uxn.y; a.u[a.N+n+1ull] = uyn.y; a.u[2ull*a.N+n+1ull] = uzn.y; }
+					}
 				}
 				// streaming part 1 in registers (kernel.cpp:1339-1345); an inactive cell keeps the bits that were read
 				const bool keep0 = !active[v], keep1 = !active[v+1];
@@ -254,7 +259,7 @@ __global__ __launch_bounds__(256) void k_collide_wide(const Args a) {
 	}
 
 	// ---- rho/u output (kernel.cpp:1581-1591): one aligned vector per field when all V cells write, else cell by cell
-	if (feat(F_UPDATE_FIELDS)) {
+	if (P == 1 && feat(F_UPDATE_FIELDS)) {
 		bool all = true, some = false;
 #pragma unroll
 		for (int v = 0; v < V; v++) { all = all && wf[v]; some = some || wf[v]; }
