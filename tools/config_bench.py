@@ -21,6 +21,9 @@ CONFIGS = {
     "tgv512_fp32_trt": dict(N=(512, 512, 512), Q=19, st="FP32", coll="TRT", feat=0),
     "tgv512_fp32_sgs": dict(N=(512, 512, 512), Q=19, st="FP32", coll="SRT", feat=F["SUBGRID"]),
     "gui512_fp16s": dict(N=(512, 512, 512), Q=19, st="FP16S", coll="SRT", feat=F["UPDATE_FIELDS"] | F["VOLUME_FORCE"] | F["EQUILIBRIUM_BOUNDARIES"] | F["SUBGRID"], mask=True, f=(0.0, 0.0, 1e-5)),
+    "chan_srt_fp16s": dict(N=(512, 512, 512), Q=19, st="FP16S", coll="SRT", feat=F["VOLUME_FORCE"] | F["SUBGRID"], mask=True, f=(2e-4, 0.0, 0.0)),
+    "chan_srt_fp16s_nomask": dict(N=(512, 512, 512), Q=19, st="FP16S", coll="SRT", feat=F["VOLUME_FORCE"] | F["SUBGRID"], f=(2e-4, 0.0, 0.0)),
+    "gui512_fp16s_nomask": dict(N=(512, 512, 512), Q=19, st="FP16S", coll="SRT", feat=F["UPDATE_FIELDS"] | F["VOLUME_FORCE"] | F["EQUILIBRIUM_BOUNDARIES"] | F["SUBGRID"], f=(0.0, 0.0, 1e-5)),
     "fp16s_1600x512x512": dict(N=(1600, 512, 512), Q=19, st="FP16S", coll="SRT", feat=0),
     "fp16s_1024": dict(N=(1024, 1024, 1024), Q=19, st="FP16S", coll="SRT", feat=0),
     "fp16s_768": dict(N=(768, 768, 768), Q=19, st="FP16S", coll="SRT", feat=0),
