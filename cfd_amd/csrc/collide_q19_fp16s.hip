@@ -7,6 +7,9 @@ collide_launch_fn select_collide_q19_fp16s(int COLL, int FEAT, int V, int P, boo
 	LBM_SPECIALISE(19, ST_FP16S, F_MOVING_BOUNDARIES)                                     // lid-driven cavity
 	LBM_SPECIALISE(19, ST_FP16S, F_VOLUME_FORCE|F_SUBGRID)                                // force-driven channel
 	LBM_SPECIALISE(19, ST_FP16S, F_UPDATE_FIELDS|F_VOLUME_FORCE|F_EQUILIBRIUM_BOUNDARIES|F_SUBGRID) // the GUI's shipped defines.hpp
+	LBM_SPECIALISE(19, ST_FP16S, F_EQUILIBRIUM_BOUNDARIES|F_SUBGRID)                           // the reference's aerodynamics setups (setup.cpp.bak: 8 of 24)
+	LBM_SPECIALISE(19, ST_FP16S, F_MOVING_BOUNDARIES|F_EQUILIBRIUM_BOUNDARIES|F_SUBGRID)       // ... with rotating parts
+	LBM_SPECIALISE(19, ST_FP16S, F_MOVING_BOUNDARIES|F_SUBGRID)                             // setup.cpp.bak: rotating geometry without inflow
 	return nullptr;
 }
 } // namespace lbm

@@ -7,6 +7,8 @@ collide_launch_fn select_collide_q19_fp32(int COLL, int FEAT, int V, int P, bool
 	LBM_SPECIALISE(19, ST_FP32, F_MOVING_BOUNDARIES)                                     // lid-driven cavity
 	LBM_SPECIALISE(19, ST_FP32, F_VOLUME_FORCE|F_SUBGRID)                                // force-driven channel
 	LBM_SPECIALISE(19, ST_FP32, F_UPDATE_FIELDS|F_VOLUME_FORCE|F_EQUILIBRIUM_BOUNDARIES|F_SUBGRID) // the GUI's shipped defines.hpp
+	LBM_SPECIALISE(19, ST_FP32, F_EQUILIBRIUM_BOUNDARIES|F_SUBGRID)                           // the reference's aerodynamics setups (setup.cpp.bak: 8 of 24)
+	LBM_SPECIALISE(19, ST_FP32, F_MOVING_BOUNDARIES|F_EQUILIBRIUM_BOUNDARIES|F_SUBGRID)       // ... with rotating parts
 	return nullptr;
 }
 } // namespace lbm
