@@ -131,6 +131,15 @@ RAGGED = {
     "fp32_260x6x6": dict(kw=dict(N=(260, 6, 6), nu=0.02), setup="tgv"),
     "fp16s_1028x4x4_wide": dict(kw=dict(N=(1028, 4, 4), nu=0.02, storage="FP16S"), setup="tgv"),
     "q15_fp16s_3dom": dict(kw=dict(N=(24, 24, 12), nu=0.02, Q=15, D=(1, 3, 1), storage="FP16S"), setup="tgv"),
+    # the feature sets of the reference's setup collection, which have kernel instances of their own
+    "aero_fp16s_eq_sgs": dict(kw=dict(N=(40, 24, 20), nu=0.005, storage="FP16S", features=("EQUILIBRIUM_BOUNDARIES", "SUBGRID")), setup="inflow"),
+    "aero_fp16c_eq_sgs": dict(kw=dict(N=(36, 20, 24), nu=0.005, storage="FP16C", features=("EQUILIBRIUM_BOUNDARIES", "SUBGRID")), setup="inflow"),
+    "aero_fp32_eq_sgs_2dom": dict(kw=dict(N=(32, 24, 32), nu=0.005, D=(1, 1, 2), features=("EQUILIBRIUM_BOUNDARIES", "SUBGRID")), setup="inflow"),
+    "aero_fp16s_mb_eq_sgs": dict(kw=dict(N=(48, 24, 24), nu=0.005, storage="FP16S", features=("MOVING_BOUNDARIES", "EQUILIBRIUM_BOUNDARIES", "SUBGRID")), setup="all"),
+    "aero_fp16c_mb_eq_sgs": dict(kw=dict(N=(48, 24, 24), nu=0.005, storage="FP16C", features=("MOVING_BOUNDARIES", "EQUILIBRIUM_BOUNDARIES", "SUBGRID")), setup="all"),
+    "aero_fp32_mb_eq_sgs": dict(kw=dict(N=(48, 24, 24), nu=0.005, features=("MOVING_BOUNDARIES", "EQUILIBRIUM_BOUNDARIES", "SUBGRID")), setup="all"),
+    "aero_fp16s_mb_sgs": dict(kw=dict(N=(32, 32, 32), nu=0.005, storage="FP16S", features=("MOVING_BOUNDARIES", "SUBGRID")), setup="cavity"),
+    "aero_fp16c_ff_eq_sgs": dict(kw=dict(N=(40, 24, 24), nu=0.005, storage="FP16C", features=("FORCE_FIELD", "EQUILIBRIUM_BOUNDARIES", "SUBGRID")), setup="sphere"),
     # degenerate lattices: every neighbour of a cell is the cell itself, or the lattice is a line / a sheet
     "fp32_1x1x1": dict(kw=dict(N=(1, 1, 1), nu=0.02), setup="tgv"),
     "fp32_2x3x1_trt": dict(kw=dict(N=(2, 3, 1), nu=0.02, collision="TRT"), setup="tgv"),
@@ -148,7 +157,7 @@ def test_ragged_shapes_and_halos(gpu, name, cells_together):
     from cfd_amd import setups
     case = RAGGED[name]
     setup = {"tgv": setups.taylor_green, "channel": CS._channel_setup, "all": CS._all_features_setup, "inflow": setups.inflow_box,
-             "cavity": setups.lid_cavity, "tgv2d": CS._tgv2d}[case["setup"]]
+             "cavity": setups.lid_cavity, "tgv2d": CS._tgv2d, "sphere": CS._sphere_setup}[case["setup"]]
     a, b = run_pair(dict(kw=case["kw"], setup=setup), tuning={"cells_together": cells_together} if cells_together else None)
     try:
         a.run(1); b.run(1)
