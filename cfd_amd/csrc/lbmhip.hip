@@ -407,6 +407,7 @@ static collide_launch_fn find_collide(const lbmhip_domain* d, int V, int P, bool
 	const int Q = (int)d->cfg.velocity_set, ST = (int)d->cfg.storage, COLL = (int)d->cfg.collision;
 	collide_launch_fn fn = nullptr;
 	for (int pass = 0; pass < 2 && !fn; pass++) { // pass 0: instance specialised for exactly this feature set; pass 1: run-time features
+		if (pass == 0 && getenv("LBMHIP_GENERIC")) continue; // diagnostic: measure the run-time-feature instances
 		const int FEAT = (pass == 0 && !fields_only) ? (int)d->cfg.features : -1;
 		if (Q == 19) fn = ST == ST_FP32 ? select_collide_q19_fp32(COLL, FEAT, V, P, fields_only) : ST == ST_FP16S ? select_collide_q19_fp16s(COLL, FEAT, V, P, fields_only) : select_collide_q19_fp16c(COLL, FEAT, V, P, fields_only);
 		else if (Q == 27) fn = ST == ST_FP32 ? select_collide_q27_fp32(COLL, FEAT, V, P, fields_only) : ST == ST_FP16S ? select_collide_q27_fp16s(COLL, FEAT, V, P, fields_only) : select_collide_q27_fp16c(COLL, FEAT, V, P, fields_only);
