@@ -42,7 +42,7 @@ struct lbmhip_domain {
 	hipEvent_t ev_start, ev_stop, ev_packed, ev_copied;
 	int cells_per_thread, cells_together, block, blocks_per_cu;
 	// launch-geometry search over the first full-lattice stream_collide launches (results do not depend on the geometry)
-	struct { int V, P, blocks_per_cu, block; float ms; } cand[64];
+	struct { int V, P, blocks_per_cu, block; float ms[3]; } cand[64]; // three timed launches per candidate, the median decides
 	int ncand, tune_launches, tune_pending, autotune, tuned, tuned_V, tuned_P, tuned_blocks_per_cu, tuned_block;
 	hipEvent_t ev_tune0, ev_tune1;
 	void* partial; // per-workgroup partial sums of the object_* reductions (kObjectSumBlocks float4)
@@ -444,7 +444,7 @@ static void build_candidates(lbmhip_domain* d) {
 	d->ncand = 0;
 	auto add = [&](int V, int P, std::initializer_list<int> caps, std::initializer_list<int> ragged_caps) {
 		if (V > 1 && (small || d->cfg.Nx%(uint32_t)V != 0u)) return;
-		auto push = [&](int c, int block) { if (d->ncand < 64) { d->cand[d->ncand].V = V; d->cand[d->ncand].P = P; d->cand[d->ncand].blocks_per_cu = c; d->cand[d->ncand].block = block; d->cand[d->ncand].ms = 1e30f; d->ncand++; } };
+		auto push = [&](int c, int block) { if (d->ncand < 64) { d->cand[d->ncand].V = V; d->cand[d->ncand].P = P; d->cand[d->ncand].blocks_per_cu = c; d->cand[d->ncand].block = block; d->cand[d->ncand].ms[0] = d->cand[d->ncand].ms[1] = d->cand[d->ncand].ms[2] = 1e30f; d->ncand++; } };
 		for (int c : caps) push(c, 0);
 		// rows that do not fill whole 256-lane workgroups: smaller workgroups waste fewer lanes at the row end
 		if ((d->cfg.Nx/(uint32_t)V)%256u != 0u && d->cfg.Nx/(uint32_t)V > 128u) for (int c : ragged_caps) { push(c, 128); push(c, 64); }
@@ -488,7 +488,7 @@ static int launch_collide_planes(lbmhip_domain* d, uint64_t t, float fx, float f
 	if (fields_only || user_set || !d->autotune) return launch_collide_geometry(d, a, V, P, blocks_per_cu, d->block, z0, z1, fields_only);
 	if (d->tuned) return launch_collide_geometry(d, a, d->tuned_V, d->tuned_P, d->tuned_blocks_per_cu, d->tuned_block, z0, z1, false);
 
-	// Geometry search: every full-lattice launch of the first 2*ncand steps runs one candidate between two events; all
+	// Geometry search: every full-lattice launch of the first 3*ncand steps runs one candidate between two events; all
 	// candidates compute the same bits, so the search is invisible in the results.  Lattices too small to time are left alone.
 	const uint64_t cells = (uint64_t)d->cfg.Nx*d->cfg.Ny*(z1-z0);
 	const bool searchable = d->N >= (1ull<<21) && 4u*(uint64_t)(z1-z0) >= 3u*(uint64_t)(d->cfg.Nz-2u*hz) && cells > 0u;
@@ -498,11 +498,12 @@ static int launch_collide_planes(lbmhip_domain* d, uint64_t t, float fx, float f
 		float ms = 0.0f;
 		HIP_TRY(hipEventSynchronize(d->ev_tune1));
 		HIP_TRY(hipEventElapsedTime(&ms, d->ev_tune0, d->ev_tune1));
-		if (ms < d->cand[d->tune_pending].ms) d->cand[d->tune_pending].ms = ms;
+		d->cand[d->tune_pending].ms[std::min(2, (d->tune_launches-1)/d->ncand)] = ms;
 		d->tune_pending = -1;
-		if (d->tune_launches >= 2*d->ncand) {
+		if (d->tune_launches >= 3*d->ncand) {
 			int best = 0;
-			for (int k = 1; k < d->ncand; k++) if (d->cand[k].ms < d->cand[best].ms) best = k;
+			auto median = [&](int k) { const float* m = d->cand[k].ms; return std::max(std::min(m[0], m[1]), std::min(std::max(m[0], m[1]), m[2])); };
+			for (int k = 1; k < d->ncand; k++) if (median(k) < median(best)) best = k;
 			d->tuned_V = d->cand[best].V; d->tuned_P = d->cand[best].P; d->tuned_blocks_per_cu = d->cand[best].blocks_per_cu; d->tuned_block = d->cand[best].block; d->tuned = 1;
 			return launch_collide_geometry(d, a, d->tuned_V, d->tuned_P, d->tuned_blocks_per_cu, d->tuned_block, z0, z1, false);
 		}

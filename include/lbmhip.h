@@ -169,8 +169,8 @@ int lbmhip_timer_stop(lbmhip_domain* domain, float* milliseconds); /* waits for 
  * 1 = a lane collides its cells one after the other, 2 = two at a time in packed FP32 arithmetic; only with 2 or 4 cells
  * per thread), "block" (0 = auto, 64..256 threads), "blocks_per_cu" (-1 = auto, 0 = no limit; caps the workgroups resident
  * per compute unit, counted in 256-lane workgroups), "autotune" (1 = default: while all these knobs are on auto, the first full-lattice
- * stream_collide launches of a lattice of at least 2^21 cells each try one launch geometry between two events and the
- * fastest is kept; every geometry computes the same bits.  0 = fixed defaults; the environment variable
+ * stream_collide launches of a lattice of at least 2^21 cells each try one launch geometry between two events (three
+ * times each) and the one with the best median is kept; every geometry computes the same bits.  0 = fixed defaults; the environment variable
  * LBMHIP_AUTOTUNE=0 has the same effect for every domain created afterwards) */
 int lbmhip_set_tuning(lbmhip_domain* domain, const char* key, int value);
 /* Reads back a launch setting ("cells_per_thread", "cells_together", "blocks_per_cu", "block", "autotune") or "tuned" (1 once
