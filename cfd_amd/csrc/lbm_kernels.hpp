@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void k_collide_wide(const Args a) {
 	const uint32_t x_hi = x+(uint32_t)V >= a.Nx ? x+(uint32_t)V-a.Nx : x+(uint32_t)V; // cell x+V, periodic
 	const uint32_t x_lo = x == 0u ? a.Nx-1u : x-1u;                                       // cell x-1, periodic
 
-	// ---- streaming part 2 (kernel.cpp:1332-1338): d[i] = raw DDFs of direction i for the 4 cells
+	// ---- streaming part 2 (kernel.cpp:1332-1338): d[i] = raw DDFs of direction i for the V cells
 	rvec d[Q];
 	raw seam[Q];
 	static_for<0, Q, 1>([&](auto I) { d[I] = rvec(0); seam[I] = 0; });
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void k_collide_wide(const Args a) {
 			const uint32_t sA = a.odd ? i : i+1, sB = a.odd ? i+1 : i;
 			d[i] = *reinterpret_cast<const rvec*>(fi+(uint64_t)sA*a.S+row0+x);
 			const raw* pn = fi+(uint64_t)sB*a.S+((uint64_t)zq[cz == 0 ? 0 : cz > 0 ? 1 : 2]*a.Ny+yq[cy == 0 ? 0 : cy > 0 ? 1 : 2])*a.Nx;
-			d[i+1] = *reinterpret_cast<const rvec*>(pn+x); // cells x..x+3 of the neighbour row; shifted below when cx != 0
+			d[i+1] = *reinterpret_cast<const rvec*>(pn+x); // cells x..x+V-1 of the neighbour row; shifted below when cx != 0
 			if constexpr (cx > 0) { if (seam_hi) seam[i+1] = pn[x_hi]; }
 			if constexpr (cx < 0) { if (seam_lo) seam[i+1] = pn[x_lo]; }
 		});
