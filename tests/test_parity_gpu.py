@@ -140,6 +140,11 @@ RAGGED = {
     "aero_fp32_mb_eq_sgs": dict(kw=dict(N=(48, 24, 24), nu=0.005, features=("MOVING_BOUNDARIES", "EQUILIBRIUM_BOUNDARIES", "SUBGRID")), setup="all"),
     "aero_fp16s_mb_sgs": dict(kw=dict(N=(32, 32, 32), nu=0.005, storage="FP16S", features=("MOVING_BOUNDARIES", "SUBGRID")), setup="cavity"),
     "aero_fp16c_ff_eq_sgs": dict(kw=dict(N=(40, 24, 24), nu=0.005, storage="FP16C", features=("FORCE_FIELD", "EQUILIBRIUM_BOUNDARIES", "SUBGRID")), setup="sphere"),
+    # the small velocity sets with extensions (run-time-feature kernels only)
+    "q15_fp32_trt_vf_sgs": dict(kw=dict(N=(28, 20, 16), nu=0.01, Q=15, collision="TRT", features=("VOLUME_FORCE", "SUBGRID"), f=(1e-4, 0.0, 0.0)), setup="channel"),
+    "q15_fp16c_all_2dom": dict(kw=dict(N=(40, 24, 16), nu=0.01, Q=15, D=(2, 1, 1), storage="FP16C",
+                                       features=("UPDATE_FIELDS", "VOLUME_FORCE", "MOVING_BOUNDARIES", "EQUILIBRIUM_BOUNDARIES", "FORCE_FIELD", "SUBGRID"), f=(1e-4, 0.0, 0.0)), setup="all"),
+    "q9_fp16s_mb_trt": dict(kw=dict(N=(48, 40, 1), nu=0.02, Q=9, storage="FP16S", collision="TRT", features=("MOVING_BOUNDARIES",)), setup="cavity2d"),
     # degenerate lattices: every neighbour of a cell is the cell itself, or the lattice is a line / a sheet
     "fp32_1x1x1": dict(kw=dict(N=(1, 1, 1), nu=0.02), setup="tgv"),
     "fp32_2x3x1_trt": dict(kw=dict(N=(2, 3, 1), nu=0.02, collision="TRT"), setup="tgv"),
@@ -150,6 +155,14 @@ RAGGED = {
 }
 
 
+def _cavity2d(lbm):
+    """2-D lid-driven cavity: solid frame, the top row moves in +x."""
+    lbm.flags[...] = 0
+    lbm.flags[:, 0, :] = 1; lbm.flags[:, -1, :] = 1; lbm.flags[:, :, 0] = 1; lbm.flags[:, :, -1] = 1
+    lbm.u[...] = 0.0
+    lbm.u[0, :, -1, :] = 0.08
+
+
 @pytest.mark.parametrize("cells_together", [0, 2])
 @pytest.mark.parametrize("name", sorted(RAGGED))
 def test_ragged_shapes_and_halos(gpu, name, cells_together):
@@ -157,7 +170,7 @@ def test_ragged_shapes_and_halos(gpu, name, cells_together):
     from cfd_amd import setups
     case = RAGGED[name]
     setup = {"tgv": setups.taylor_green, "channel": CS._channel_setup, "all": CS._all_features_setup, "inflow": setups.inflow_box,
-             "cavity": setups.lid_cavity, "tgv2d": CS._tgv2d, "sphere": CS._sphere_setup}[case["setup"]]
+             "cavity": setups.lid_cavity, "tgv2d": CS._tgv2d, "sphere": CS._sphere_setup, "cavity2d": _cavity2d}[case["setup"]]
     a, b = run_pair(dict(kw=case["kw"], setup=setup), tuning={"cells_together": cells_together} if cells_together else None)
     try:
         a.run(1); b.run(1)
