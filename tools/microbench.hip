@@ -156,6 +156,38 @@ template <int V, int SHIFT, int WORK> __global__ __launch_bounds__(256) void k_r
 	}
 }
 
+// Blocked layout: 64 consecutive cells x 19 DDFs form one contiguous 4864-byte block, addr(i, n) = ((n/64)*19+i)*64+n%64.
+// Same slot pattern as k_rmw MODE 1 (odd slots of each pair at the neighbour cell), one cell per lane, in place.
+__global__ __launch_bounds__(256) void k_rmw_blocked(float* fi, unsigned Nx, unsigned Ny, unsigned Nz, unsigned xchunks, float s) {
+	const unsigned chunk = blockIdx.x%xchunks, r = blockIdx.x/xchunks, z = r/Ny, y = r%Ny;
+	const unsigned x = chunk*blockDim.x+threadIdx.x;
+	if (x >= Nx) return;
+	const unsigned yq[3] = {y, y+1 == Ny ? 0 : y+1, y == 0 ? Ny-1 : y-1}, zq[3] = {z, z+1 == Nz ? 0 : z+1, z == 0 ? Nz-1 : z-1};
+	constexpr int cx[9] = {1,0,0,1,1,0,1,1,0}, cy[9] = {0,1,0,1,0,1,-1,0,1}, cz[9] = {0,0,1,0,1,1,0,-1,-1};
+	auto addr = [&](unsigned i, size_t n) -> size_t { return ((n>>6)*19u+i)*64u+(n&63u); };
+	const size_t n = ((size_t)z*Ny+y)*Nx+x;
+	const unsigned xp = x+1 == Nx ? 0 : x+1;
+	float f[19];
+	size_t a[19];
+	a[0] = addr(0, n);
+#pragma unroll
+	for (int k = 0; k < 9; k++) {
+		a[1+2*k] = addr(2+2*k, n);
+		const size_t nb = ((size_t)zq[cz[k] == 0 ? 0 : cz[k] > 0 ? 1 : 2]*Ny+yq[cy[k] == 0 ? 0 : cy[k] > 0 ? 1 : 2])*Nx+(cx[k] ? xp : x);
+		a[2+2*k] = addr(1+2*k, nb);
+	}
+#pragma unroll
+	for (int i = 0; i < 19; i++) f[i] = fi[a[i]];
+	float sum = f[0];
+#pragma unroll
+	for (int i = 1; i < 19; i++) sum += f[i];
+#pragma unroll
+	for (int i = 0; i < 19; i++) f[i] = f[i]*s+sum*1e-3f;
+	fi[a[0]] = f[0];
+#pragma unroll
+	for (int k = 0; k < 9; k++) { fi[a[1+2*k]] = f[2+2*k]; fi[a[2+2*k]] = f[1+2*k]; }
+}
+
 template <class F> float time_ms(F launch, int reps) {
 	hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
 	launch(); launch();
@@ -209,6 +241,16 @@ int main(int argc, char** argv) {
 		CHECK(hipMemset(fi, 0, (N+padmax)*19*sizeof(float)));
 	}
 	CHECK(hipMemset(fi, 0, (N+padmax)*19*sizeof(float)));
+	if (argc > 3 && !strcmp(argv[3], "blocked")) { // blocked (64 cells x 19 DDFs) layout against the stream layout, one cell per lane
+		for (unsigned k : {0u, 2u, 3u, 4u, 6u, 8u}) {
+			const unsigned b = 256u, xchunks = (n+b-1)/b;
+			const unsigned lds = k ? (160u*1024u/k)&~255u : 0u;
+			const float ms = time_ms([&]() { hipLaunchKernelGGL(k_rmw_blocked, dim3(xchunks*n*n), dim3(b), lds, 0, fi, n, n, n, xchunks, 0.999f); }, 10);
+			printf("blocked 64x19 layout blocks/CU<=%u: %.3f ms  %.0f GB/s (%.1f%%)\n", k, ms, 152.0*N/ms/1e6, 152.0*N/ms/1e6/80); fflush(stdout);
+			run<1, 1, false>(fi, N, n, 256u, 0, k);
+		}
+		return 0;
+	}
 	if (argc > 3 && !strcmp(argv[3], "pad")) { // stream-stride padding sweep for the FP32 one-cell-per-lane pattern
 		for (size_t pad : {(size_t)0, (size_t)32, (size_t)64, (size_t)128, (size_t)256, (size_t)512, (size_t)1024, (size_t)2048, (size_t)4096, (size_t)4160, (size_t)8192, (size_t)8256, (size_t)16384, (size_t)16448, (size_t)65536, (size_t)65600, (size_t)262144, (size_t)262208, (size_t)524288, (size_t)1048576-64})
 			for (unsigned k : {2u, 3u}) run<1, 1, false>(fi, N, n, 256u, pad, k);
