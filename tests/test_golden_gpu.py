@@ -115,8 +115,11 @@ from tests.voxel_cases import VOXEL_CASES, build_mesh  # noqa: E402
 from tests.test_oracle_golden import GOLDEN  # noqa: E402
 
 
+@pytest.mark.parametrize("pad", [0, 4160])
 @pytest.mark.parametrize("name", sorted(VOXEL_CASES))
-def test_hip_voxelizer_reproduces_reference_fixture(gpu, name):
+def test_hip_voxelizer_reproduces_reference_fixture(gpu, monkeypatch, name, pad):
+    if pad:
+        monkeypatch.setenv("LBMHIP_PAD", str(pad))  # DDF streams a padded stride apart: the moving-mesh path writes DDFs
     case = VOXEL_CASES[name]
     z = np.load(os.path.join(GOLDEN, "voxel_" + name + ".npz"), allow_pickle=False)
     with cfd_amd.LBM(case["N"], 0.01, D=case["D"]) as lbm:
