@@ -3,6 +3,7 @@
 #include "../../include/lbmhip.h"
 #define LBM_SMALL_KERNELS
 #include "lbm_dispatch.hpp"
+#include "lbm_jit.hpp"
 
 #include <cstdarg>
 #include <cstdio>
@@ -45,6 +46,7 @@ struct lbmhip_domain {
 	struct { int V, P, blocks_per_cu, block; float ms[3]; } cand[64]; // three timed launches per candidate, the median decides
 	int ncand, tune_launches, tune_pending, autotune, tuned, tuned_V, tuned_P, tuned_blocks_per_cu, tuned_block;
 	hipEvent_t ev_tune0, ev_tune1;
+	int uses_jit;  // the last stream_collide launch ran a kernel compiled at run time for this domain's feature set
 	void* partial; // per-workgroup partial sums of the object_* reductions (kObjectSumBlocks float4)
 	float w;
 };
@@ -397,23 +399,33 @@ int lbmhip_get_tuning(lbmhip_domain* d, const char* key, int* value) {
 	if (!strcmp(key, "block")) { *value = d->tuned ? d->tuned_block : d->block; return 0; }
 	if (!strcmp(key, "autotune")) { *value = d->autotune; return 0; }
 	if (!strcmp(key, "tuned")) { *value = d->tuned; return 0; }
+	if (!strcmp(key, "jit")) { *value = d->uses_jit; return 0; }
 	return fail("unknown tuning key '%s'", key);
 }
 
 } // extern "C"
 
 // ---------------------------------------------------------------------------------------------- launches
-static collide_launch_fn find_collide(const lbmhip_domain* d, int V, int P, bool fields_only) {
+// A stream_collide / update_fields instance: precompiled (fn), or compiled at run time for exactly this feature set (jit)
+struct CollideKernel { collide_launch_fn fn; hipFunction_t jit; };
+static CollideKernel find_collide(const lbmhip_domain* d, int V, int P, bool fields_only) {
 	const int Q = (int)d->cfg.velocity_set, ST = (int)d->cfg.storage, COLL = (int)d->cfg.collision;
+	const bool small = Q == 9 || Q == 15;
 	collide_launch_fn fn = nullptr;
-	for (int pass = 0; pass < 2 && !fn; pass++) { // pass 0: instance specialised for exactly this feature set; pass 1: run-time features
-		if (pass == 0 && getenv("LBMHIP_GENERIC")) continue; // diagnostic: measure the run-time-feature instances
-		const int FEAT = (pass == 0 && !fields_only) ? (int)d->cfg.features : -1;
+	for (int pass = 0; pass < 3 && !fn; pass++) { // 0: precompiled for exactly this feature set; 1: compiled now for it; 2: run-time features
+		if (pass < 2 && (fields_only || getenv("LBMHIP_GENERIC"))) continue; // LBMHIP_GENERIC: diagnostic, measures the run-time-feature instances
+		if (pass == 1) {
+			const lbm::jit::Instance* inst = lbm::jit::instance(d->cfg.device, Q, ST, COLL, (int)d->cfg.features, small);
+			hipFunction_t f = inst ? inst->fn[lbm::jit::geometry_index(small ? 1 : V, P)] : nullptr;
+			if (f) return CollideKernel{nullptr, f};
+			continue;
+		}
+		const int FEAT = pass == 0 ? (int)d->cfg.features : -1;
 		if (Q == 19) fn = ST == ST_FP32 ? select_collide_q19_fp32(COLL, FEAT, V, P, fields_only) : ST == ST_FP16S ? select_collide_q19_fp16s(COLL, FEAT, V, P, fields_only) : select_collide_q19_fp16c(COLL, FEAT, V, P, fields_only);
 		else if (Q == 27) fn = ST == ST_FP32 ? select_collide_q27_fp32(COLL, FEAT, V, P, fields_only) : ST == ST_FP16S ? select_collide_q27_fp16s(COLL, FEAT, V, P, fields_only) : select_collide_q27_fp16c(COLL, FEAT, V, P, fields_only);
 		else fn = select_collide_small(Q, ST, COLL, FEAT, V, P, fields_only);
 	}
-	return fn;
+	return CollideKernel{fn, nullptr};
 }
 
 // Default launch geometry.  Measured on MI355X at 512^3: plain FP32 D3Q19 is fastest with one cell per lane (dword
@@ -467,11 +479,15 @@ static int launch_collide_geometry(lbmhip_domain* d, const Args& base, int V, in
 	// one grid dimension carries at most 2^32-1 work-items: x-chunks and y go to grid.x, lattice planes to grid.y
 	const uint64_t blocks_x = (uint64_t)a.xchunks*d->cfg.Ny;
 	NEED(blocks_x*block < 0xFFFFFFFFull && (z1-z0) <= 65535u, "lattice too large for one launch (%llu x %u workgroups)", (unsigned long long)blocks_x, z1-z0);
-	collide_launch_fn fn = find_collide(d, V, P, fields_only);
-	NEED(fn, "no compiled kernel for D?Q%u storage %u collision %u", d->cfg.velocity_set, d->cfg.storage, d->cfg.collision);
+	const CollideKernel kernel = find_collide(d, V, P, fields_only);
+	NEED(kernel.fn || kernel.jit, "no compiled kernel for D?Q%u storage %u collision %u", d->cfg.velocity_set, d->cfg.storage, d->cfg.collision);
 	// dynamic LDS is not used by the kernel; reserving it caps the workgroups resident per CU (160 KiB LDS per CU)
 	const uint32_t lds = blocks_per_cu > 0 ? ((160u*1024u/(uint32_t)blocks_per_cu)&~255u) : 0u;
-	HIP_TRY(fn(a, dim3((uint32_t)blocks_x, z1-z0), dim3(block), lds, d->stream));
+	if (kernel.jit) {
+		void* params[] = {(void*)&a};
+		HIP_TRY(hipModuleLaunchKernel(kernel.jit, (uint32_t)blocks_x, z1-z0, 1u, block, 1u, 1u, lds, d->stream, params, nullptr));
+	} else HIP_TRY(kernel.fn(a, dim3((uint32_t)blocks_x, z1-z0), dim3(block), lds, d->stream));
+	if (!fields_only) d->uses_jit = kernel.jit != nullptr;
 	return 0;
 }
 

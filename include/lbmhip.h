@@ -173,8 +173,13 @@ int lbmhip_timer_stop(lbmhip_domain* domain, float* milliseconds); /* waits for 
  * times each) and the one with the best median is kept; every geometry computes the same bits.  0 = fixed defaults; the environment variable
  * LBMHIP_AUTOTUNE=0 has the same effect for every domain created afterwards) */
 int lbmhip_set_tuning(lbmhip_domain* domain, const char* key, int value);
-/* Reads back a launch setting ("cells_per_thread", "cells_together", "blocks_per_cu", "block", "autotune") or "tuned" (1 once
- * the geometry search has finished; the launch settings then report its choice).  No counterpart in the reference. */
+/* Reads back a launch setting ("cells_per_thread", "cells_together", "blocks_per_cu", "block", "autotune"), "tuned" (1 once
+ * the geometry search has finished; the launch settings then report its choice) or "jit" (1 when the last stream_collide
+ * ran a kernel compiled at run time).  No counterpart in the reference.
+ * Kernel instances: the library carries compiled stream_collide instances for the common feature sets; for any other set the
+ * first launch compiles an instance for exactly that set with hipRTC (2-4 s once per process and device), the way the
+ * reference compiles its OpenCL code with the configured extensions (lbm.cpp:424-665).  Without hipRTC, or with
+ * LBMHIP_JIT=0, an instance that tests the feature bits at run time is used (same results, 10-50 % slower). */
 int lbmhip_get_tuning(lbmhip_domain* domain, const char* key, int* value);
 
 #ifdef __cplusplus

@@ -253,3 +253,25 @@ def test_stream_stride_default_choice(gpu, monkeypatch):
             assert stride.value - n == want_pad, (dims, D, stride.value - n)
         finally:
             dom.close()
+
+
+def test_runtime_compiled_kernels(gpu, monkeypatch):
+    """A feature set without a precompiled instance is compiled at its first launch (hipRTC) for exactly that set, like the
+    reference compiles its OpenCL code with the configured extensions; with LBMHIP_JIT=0 the run-time-feature instance
+    runs instead.  Both must give the oracle's bits."""
+    case = CASES["all_fp16s_trt_2dom"]
+    monkeypatch.delenv("LBMHIP_JIT", raising=False)
+    a, ref = run_pair(case)
+    a.run(case["steps"])                      # the kernel is chosen at the first launch
+    jit_a = a.get_tuning("jit")
+    monkeypatch.setenv("LBMHIP_JIT", "0")
+    b = cfd_amd.LBM(**case["kw"])
+    case["setup"](b)
+    try:
+        b.run(case["steps"]); ref.run(case["steps"])
+        assert jit_a == 1, "hipRTC path not taken (LBMHIP_JIT_VERBOSE=1 prints the reason)"
+        assert b.get_tuning("jit") == 0
+        compare(a, ref, "run-time compiled")
+        compare(b, ref, "run-time features")
+    finally:
+        a.close(); b.close()
