@@ -188,6 +188,46 @@ __global__ __launch_bounds__(256) void k_rmw_blocked(float* fi, unsigned Nx, uns
 	for (int k = 0; k < 9; k++) { fi[a[1+2*k]] = f[2+2*k]; fi[a[2+2*k]] = f[1+2*k]; }
 }
 
+// k_rmw MODE 1, one cell per lane, with the stores (SCOPE_ST) and loads (SCOPE_LD) issued as relaxed atomics of a wider
+// memory scope: 0 = ordinary access, 1 = agent scope, 2 = system scope (write-through / cache-bypassing coherence bits)
+template <int SCOPE_LD, int SCOPE_ST> __global__ __launch_bounds__(256) void k_rmw_scope(float* fi, size_t N, unsigned Nx, unsigned Ny, unsigned Nz, unsigned xchunks, float s) {
+	const unsigned chunk = blockIdx.x%xchunks, r = blockIdx.x/xchunks, z = r/Ny, y = r%Ny;
+	const unsigned x = chunk*blockDim.x+threadIdx.x;
+	if (x >= Nx) return;
+	const unsigned yq[3] = {y, y+1 == Ny ? 0 : y+1, y == 0 ? Ny-1 : y-1}, zq[3] = {z, z+1 == Nz ? 0 : z+1, z == 0 ? Nz-1 : z-1};
+	const size_t row0 = ((size_t)z*Ny+y)*Nx;
+	constexpr int cx[9] = {1,0,0,1,1,0,1,1,0}, cy[9] = {0,1,0,1,0,1,-1,0,1}, cz[9] = {0,0,1,0,1,1,0,-1,-1};
+	const unsigned xp = x+1 == Nx ? 0 : x+1;
+	auto ld = [&](float* p) -> float {
+		if constexpr (SCOPE_LD == 1) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		else if constexpr (SCOPE_LD == 2) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		else return *p;
+	};
+	auto st = [&](float* p, float v) {
+		if constexpr (SCOPE_ST == 1) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		else if constexpr (SCOPE_ST == 2) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		else *p = v;
+	};
+	float* a[19];
+	a[0] = fi+row0+x;
+#pragma unroll
+	for (int k = 0; k < 9; k++) {
+		a[1+2*k] = fi+(size_t)(2+2*k)*N+row0+x;
+		a[2+2*k] = fi+(size_t)(1+2*k)*N+((size_t)zq[cz[k] == 0 ? 0 : cz[k] > 0 ? 1 : 2]*Ny+yq[cy[k] == 0 ? 0 : cy[k] > 0 ? 1 : 2])*Nx+(cx[k] ? xp : x);
+	}
+	float f[19];
+#pragma unroll
+	for (int i = 0; i < 19; i++) f[i] = ld(a[i]);
+	float sum = f[0];
+#pragma unroll
+	for (int i = 1; i < 19; i++) sum += f[i];
+#pragma unroll
+	for (int i = 0; i < 19; i++) f[i] = f[i]*s+sum*1e-3f;
+	st(a[0], f[0]);
+#pragma unroll
+	for (int k = 0; k < 9; k++) { st(a[1+2*k], f[2+2*k]); st(a[2+2*k], f[1+2*k]); }
+}
+
 template <class F> float time_ms(F launch, int reps) {
 	hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
 	launch(); launch();
@@ -241,6 +281,18 @@ int main(int argc, char** argv) {
 		CHECK(hipMemset(fi, 0, (N+padmax)*19*sizeof(float)));
 	}
 	CHECK(hipMemset(fi, 0, (N+padmax)*19*sizeof(float)));
+	if (argc > 3 && !strcmp(argv[3], "scope")) { // memory scope of the accesses: ordinary, agent, system
+		auto one = [&](auto kern, const char* what) {
+			for (unsigned k : {2u, 3u}) {
+				const unsigned b = 256u, xchunks = (n+b-1)/b, lds = (160u*1024u/k)&~255u;
+				const float ms = time_ms([&]() { hipLaunchKernelGGL(kern, dim3(xchunks*n*n), dim3(b), lds, 0, fi, N, n, n, n, xchunks, 0.999f); }, 10);
+				printf("scope %-28s blocks/CU<=%u: %.3f ms  %.0f GB/s (%.1f%%)\n", what, k, ms, 152.0*N/ms/1e6, 152.0*N/ms/1e6/80); fflush(stdout);
+			}
+		};
+		one(k_rmw_scope<0, 0>, "load plain, store plain"); one(k_rmw_scope<0, 1>, "load plain, store agent"); one(k_rmw_scope<0, 2>, "load plain, store system");
+		one(k_rmw_scope<1, 0>, "load agent, store plain"); one(k_rmw_scope<2, 0>, "load system, store plain"); one(k_rmw_scope<1, 1>, "load agent, store agent"); one(k_rmw_scope<2, 2>, "load system, store system");
+		return 0;
+	}
 	if (argc > 3 && !strcmp(argv[3], "blocked")) { // blocked (64 cells x 19 DDFs) layout against the stream layout, one cell per lane
 		for (unsigned k : {0u, 2u, 3u, 4u, 6u, 8u}) {
 			const unsigned b = 256u, xchunks = (n+b-1)/b;
