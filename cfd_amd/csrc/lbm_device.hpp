@@ -120,44 +120,109 @@ template <> struct Store<ST_FP32> {
 	static __device__ __forceinline__ float2v decode2(raw2 r) { return r; }
 	static __device__ __forceinline__ raw2 encode2(float2v x) { return x; }
 	static __device__ __forceinline__ raw2 merge2(raw2 old, raw2 val, bool keep0, bool keep1) { raw2 r; r.x = keep0 ? old.x : val.x; r.y = keep1 ? old.y : val.y; return r; }
+	// encoding in two stages (see FP16C): nothing to prepare here
+	template <int N, class R> static __device__ __forceinline__ void prescale(R*) {}
+	static __device__ __forceinline__ raw encode_scaled(float x) { return encode(x); }
+	static __device__ __forceinline__ raw2 encode2_scaled(float2v x) { return encode2(x); }
 };
 // FP16S: IEEE half scaled by 2^15 (lbm.cpp:572-575)
 template <> struct Store<ST_FP16S> {
 	using raw = uint16_t;
 	static __device__ __forceinline__ float decode(raw r) { return __half2float(__ushort_as_half(r))*3.0517578E-5f; }
-	static __device__ __forceinline__ raw encode(float x) { return __half_as_ushort(__float2half_rn(x*32768.0f)); }
+	// x*2^15 rounded to half once (v_fma_mixlo_f16; the scaling is exact, so this is the reference's multiply followed by
+	// vstore_half_rte).  The addend is -0: the compiler's own fusion of the multiply and the conversion adds +0, which turns
+	// a stored -0 into +0.
+	static __device__ __forceinline__ raw encode(float x) {
+		uint32_t r;
+		asm("v_fma_mixlo_f16 %0, %1, %2, neg(0)" : "=v"(r) : "v"(x), "s"(32768.0f));
+		return (raw)r;
+	}
 	// two neighbouring cells at once: one dword, the first cell in its low half; conversion with v_cvt_pk_f16_f32 (round to nearest even)
 	typedef uint32_t raw2;
 	static __device__ __forceinline__ float2v decode2(raw2 r) { return __builtin_convertvector(__builtin_bit_cast(half2v, r), float2v)*3.0517578E-5f; }
 	static __device__ __forceinline__ raw2 encode2(float2v x) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(x*32768.0f, half2v)); }
 	static __device__ __forceinline__ raw2 merge2(raw2 old, raw2 val, bool keep0, bool keep1) { const uint32_t m = (keep0 ? 0x0000FFFFu : 0u)|(keep1 ? 0xFFFF0000u : 0u); return (old&m)|(val&~m); }
+	template <int N, class R> static __device__ __forceinline__ void prescale(R*) {}
+	static __device__ __forceinline__ raw encode_scaled(float x) { return encode(x); }
+	static __device__ __forceinline__ raw2 encode2_scaled(float2v x) { return encode2(x); }
 };
-// FP16C: 1 sign, 4 exponent (bias 15), 11 mantissa bits, subnormals below 2^-14 (kernel.cpp:858-869)
+// FP16C: 1 sign, 4 exponent (bias 15), 11 mantissa bits, subnormals below 2^-14 (kernel.cpp:858-869).
+//
+// Both directions go through FP32 values scaled by 2^-112, whose FP32 bit pattern IS the 16-bit code shifted left by 12:
+// the code's exponent field (bias 15) sits in the low four bits of the FP32 exponent field (bias 127 = 15+112) and a code
+// with exponent 0 (value mantissa * 2^-25) is an FP32 subnormal.  FP32 subnormals are kept (the default mode of HIP on
+// gfx9), so one multiply normalises or denormalises exactly and no case distinction is left:
+//   decode: move sign, exponent and mantissa into place, multiply by 2^112 (exact).
+//   encode: multiply by 2^-112 ROUNDING TOWARDS ZERO, add half of the last kept bit (0x800) to the bit pattern, cut.
+//           In the normal range the multiply is exact and this is the reference's add-and-truncate; below 2^-14 the
+//           truncating multiply is the reference's right shift of the mantissa (kernel.cpp:868) and the add its
+//           round-half-up.  Identical bits for every finite float (checked for all 2^32 inputs, see tests); only the
+//           payload of a NaN differs.
+// The rounding mode is a wave-wide register (MODE.fp_round), so the multiplies run inside asm blocks that set it to
+// round-towards-zero and back; nothing the compiler schedules can land between the two s_setreg of a block.
+#define LBM_RTZ_ON "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\ts_nop 1\n\t"
+#define LBM_RTZ_OFF "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+#define LBM_RTZ_MUL(k) "v_mul_f32 %" #k ", 0x07800000, %" #k "\n\t"
+#define LBM_RTZ_PKMUL(k, s) "v_pk_mul_f32 %" #k ", %" #k ", %" #s "\n\t"
+// p[0..N) *= 2^-112, rounded towards zero; N <= 9 per asm block
+template <int N> __device__ __forceinline__ void rtz_scale_block(float* p) {
+	static_assert(N >= 1 && N <= 9, "block of 1..9 values");
+	if constexpr (N == 1) asm volatile(LBM_RTZ_ON LBM_RTZ_MUL(0) LBM_RTZ_OFF : "+v"(p[0]));
+	else if constexpr (N == 2) asm volatile(LBM_RTZ_ON LBM_RTZ_MUL(0) LBM_RTZ_MUL(1) LBM_RTZ_OFF : "+v"(p[0]), "+v"(p[1]));
+	else if constexpr (N == 3) asm volatile(LBM_RTZ_ON LBM_RTZ_MUL(0) LBM_RTZ_MUL(1) LBM_RTZ_MUL(2) LBM_RTZ_OFF : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]));
+	else if constexpr (N == 4) asm volatile(LBM_RTZ_ON LBM_RTZ_MUL(0) LBM_RTZ_MUL(1) LBM_RTZ_MUL(2) LBM_RTZ_MUL(3) LBM_RTZ_OFF : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]));
+	else if constexpr (N == 5) asm volatile(LBM_RTZ_ON LBM_RTZ_MUL(0) LBM_RTZ_MUL(1) LBM_RTZ_MUL(2) LBM_RTZ_MUL(3) LBM_RTZ_MUL(4) LBM_RTZ_OFF : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]));
+	else if constexpr (N == 6) asm volatile(LBM_RTZ_ON LBM_RTZ_MUL(0) LBM_RTZ_MUL(1) LBM_RTZ_MUL(2) LBM_RTZ_MUL(3) LBM_RTZ_MUL(4) LBM_RTZ_MUL(5) LBM_RTZ_OFF : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]));
+	else if constexpr (N == 7) asm volatile(LBM_RTZ_ON LBM_RTZ_MUL(0) LBM_RTZ_MUL(1) LBM_RTZ_MUL(2) LBM_RTZ_MUL(3) LBM_RTZ_MUL(4) LBM_RTZ_MUL(5) LBM_RTZ_MUL(6) LBM_RTZ_OFF : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]));
+	else if constexpr (N == 8) asm volatile(LBM_RTZ_ON LBM_RTZ_MUL(0) LBM_RTZ_MUL(1) LBM_RTZ_MUL(2) LBM_RTZ_MUL(3) LBM_RTZ_MUL(4) LBM_RTZ_MUL(5) LBM_RTZ_MUL(6) LBM_RTZ_MUL(7) LBM_RTZ_OFF : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]));
+	else asm volatile(LBM_RTZ_ON LBM_RTZ_MUL(0) LBM_RTZ_MUL(1) LBM_RTZ_MUL(2) LBM_RTZ_MUL(3) LBM_RTZ_MUL(4) LBM_RTZ_MUL(5) LBM_RTZ_MUL(6) LBM_RTZ_MUL(7) LBM_RTZ_MUL(8) LBM_RTZ_OFF : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]), "+v"(p[8]));
+}
+// the same for pairs of cells (one packed multiply per pair); s = {2^-112, 2^-112}
+template <int N> __device__ __forceinline__ void rtz_scale_block(float2v* p) {
+	static_assert(N >= 1 && N <= 9, "block of 1..9 pairs");
+	const float2v s = {0x1p-112f, 0x1p-112f};
+	if constexpr (N == 1) asm volatile(LBM_RTZ_ON LBM_RTZ_PKMUL(0, 1) LBM_RTZ_OFF : "+v"(p[0]) : "v"(s));
+	else if constexpr (N == 2) asm volatile(LBM_RTZ_ON LBM_RTZ_PKMUL(0, 2) LBM_RTZ_PKMUL(1, 2) LBM_RTZ_OFF : "+v"(p[0]), "+v"(p[1]) : "v"(s));
+	else if constexpr (N == 3) asm volatile(LBM_RTZ_ON LBM_RTZ_PKMUL(0, 3) LBM_RTZ_PKMUL(1, 3) LBM_RTZ_PKMUL(2, 3) LBM_RTZ_OFF : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]) : "v"(s));
+	else if constexpr (N == 4) asm volatile(LBM_RTZ_ON LBM_RTZ_PKMUL(0, 4) LBM_RTZ_PKMUL(1, 4) LBM_RTZ_PKMUL(2, 4) LBM_RTZ_PKMUL(3, 4) LBM_RTZ_OFF : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]) : "v"(s));
+	else if constexpr (N == 5) asm volatile(LBM_RTZ_ON LBM_RTZ_PKMUL(0, 5) LBM_RTZ_PKMUL(1, 5) LBM_RTZ_PKMUL(2, 5) LBM_RTZ_PKMUL(3, 5) LBM_RTZ_PKMUL(4, 5) LBM_RTZ_OFF : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]) : "v"(s));
+	else if constexpr (N == 6) asm volatile(LBM_RTZ_ON LBM_RTZ_PKMUL(0, 6) LBM_RTZ_PKMUL(1, 6) LBM_RTZ_PKMUL(2, 6) LBM_RTZ_PKMUL(3, 6) LBM_RTZ_PKMUL(4, 6) LBM_RTZ_PKMUL(5, 6) LBM_RTZ_OFF : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]) : "v"(s));
+	else if constexpr (N == 7) asm volatile(LBM_RTZ_ON LBM_RTZ_PKMUL(0, 7) LBM_RTZ_PKMUL(1, 7) LBM_RTZ_PKMUL(2, 7) LBM_RTZ_PKMUL(3, 7) LBM_RTZ_PKMUL(4, 7) LBM_RTZ_PKMUL(5, 7) LBM_RTZ_PKMUL(6, 7) LBM_RTZ_OFF : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]) : "v"(s));
+	else if constexpr (N == 8) asm volatile(LBM_RTZ_ON LBM_RTZ_PKMUL(0, 8) LBM_RTZ_PKMUL(1, 8) LBM_RTZ_PKMUL(2, 8) LBM_RTZ_PKMUL(3, 8) LBM_RTZ_PKMUL(4, 8) LBM_RTZ_PKMUL(5, 8) LBM_RTZ_PKMUL(6, 8) LBM_RTZ_PKMUL(7, 8) LBM_RTZ_OFF : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]) : "v"(s));
+	else asm volatile(LBM_RTZ_ON LBM_RTZ_PKMUL(0, 9) LBM_RTZ_PKMUL(1, 9) LBM_RTZ_PKMUL(2, 9) LBM_RTZ_PKMUL(3, 9) LBM_RTZ_PKMUL(4, 9) LBM_RTZ_PKMUL(5, 9) LBM_RTZ_PKMUL(6, 9) LBM_RTZ_PKMUL(7, 9) LBM_RTZ_PKMUL(8, 9) LBM_RTZ_OFF : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]), "+v"(p[8]) : "v"(s));
+}
+template <int N, class R> __device__ __forceinline__ void rtz_scale(R* p) { // all N values, nine per block
+	static_for<0, N/9, 1>([&](auto B) { rtz_scale_block<9>(p+9*(int)B); });
+	if constexpr (N%9 != 0) rtz_scale_block<N%9>(p+N/9*9);
+}
 template <> struct Store<ST_FP16C> {
 	using raw = uint16_t;
-	// exponent and mantissa moved into the FP32 fields give x*2^-112 (an FP32 subnormal when e=0); the multiply by
-	// 2^112 is exact and normalises both cases, so no branch is needed (FP32 subnormals are kept in the default mode)
 	static __device__ __forceinline__ float decode(raw r) {
-		const uint32_t h = r;
-		const float v = __uint_as_float((h&0x7FFFu)<<12)*0x1p112f;
-		return __uint_as_float(__float_as_uint(v)|((h&0x8000u)<<16));
+		const int32_t t = (int32_t)((uint32_t)r<<16)>>4; // sign | sign copies | exponent | mantissa
+		return __uint_as_float((uint32_t)t&0x87FFF000u)*0x1p112f;
 	}
-	// round by adding half of the last kept mantissa bit and truncating; subnormal results restore the implicit one first
-	static __device__ __forceinline__ raw encode(float x) {
-		const uint32_t b = __float_as_uint(x)+0x00000800u, a = b&0x7FFFFFFFu, e = a>>23;
-		const uint32_t normal = ((a>>12)-0x38000u)&0x7FFFu;
-		const uint32_t subnormal = ((((0x007FF800u+(a&0x007FFFFFu))>>((124u-e)&31u))+1u)>>1);
-		return (raw)(((b>>16)&0x8000u)|(e > 112u ? normal : e > 100u ? subnormal : 0u));
+	// the 16-bit code of a value that was already multiplied by 2^-112 towards zero (rtz_scale)
+	static __device__ __forceinline__ raw encode_scaled(float w) {
+		const uint32_t u = __float_as_uint(w)+0x00000800u;
+		return (raw)(((u>>12)&0x7FFFu)|((u>>16)&0x8000u));
 	}
+	static __device__ __forceinline__ raw encode(float x) { rtz_scale_block<1>(&x); return encode_scaled(x); }
+	template <int N> static __device__ __forceinline__ void prescale(float* f) { rtz_scale<N>(f); }
+	template <int N> static __device__ __forceinline__ void prescale(float2v* f) { rtz_scale<N>(f); }
 	typedef uint32_t raw2;
 	static __device__ __forceinline__ float2v decode2(raw2 r) {
-		const uint32_t h0 = r&0xFFFFu, h1 = r>>16;
-		float2v v; v.x = __uint_as_float((h0&0x7FFFu)<<12); v.y = __uint_as_float((h1&0x7FFFu)<<12);
-		v = v*0x1p112f;
-		v.x = __uint_as_float(__float_as_uint(v.x)|((h0&0x8000u)<<16)); v.y = __uint_as_float(__float_as_uint(v.y)|((h1&0x8000u)<<16));
-		return v;
+		float2v v;
+		v.x = __uint_as_float((uint32_t)((int32_t)(r<<16)>>4)&0x87FFF000u);
+		v.y = __uint_as_float((uint32_t)((int32_t)r>>4)&0x87FFF000u);
+		return v*0x1p112f;
 	}
-	static __device__ __forceinline__ raw2 encode2(float2v x) { return (uint32_t)encode(x.x)|((uint32_t)encode(x.y)<<16); }
+	static __device__ __forceinline__ raw2 encode2_scaled(float2v w) {
+		const uint32_t u0 = __float_as_uint(w.x)+0x00000800u, u1 = __float_as_uint(w.y)+0x00000800u;
+		const uint32_t lo = ((u0>>12)&0x7FFFu)|((u0>>16)&0x8000u);
+		const uint32_t hi = ((u1<<4)&0x7FFF0000u)|(u1&0x80000000u);
+		return hi|lo;
+	}
+	static __device__ __forceinline__ raw2 encode2(float2v x) { rtz_scale_block<1>(&x); return encode2_scaled(x); }
 	static __device__ __forceinline__ raw2 merge2(raw2 old, raw2 val, bool keep0, bool keep1) { const uint32_t m = (keep0 ? 0x0000FFFFu : 0u)|(keep1 ? 0xFFFF0000u : 0u); return (old&m)|(val&~m); }
 };
 

@@ -79,11 +79,12 @@ __global__ __launch_bounds__(256) void k_collide(const Args a) {
 		if (feat(F_MOVING_BOUNDARIES) && bo == TYPE_MS) apply_moving_boundaries<Q>(f, a, x, yq, zq);
 		collide<Q, COLL, FIELDS_ONLY>(f, feat, &bo, a, n, rhon, uxn, uyn, uzn, &write_fields);
 		if constexpr (!FIELDS_ONLY) { // streaming part 1 in registers: the slot that held f[i] receives f[i+1] and vice versa (kernel.cpp:1339-1345)
-			r[0] = S::encode(f[0]);
+			S::template prescale<Q>(f);
+			r[0] = S::encode_scaled(f[0]);
 			static_for<1, Q, 2>([&](auto I) {
 				constexpr int i = I;
-				r[i] = S::encode(f[i+1]);
-				r[i+1] = S::encode(f[i]);
+				r[i] = S::encode_scaled(f[i+1]);
+				r[i+1] = S::encode_scaled(f[i]);
 			});
 		}
 	}
@@ -225,11 +226,12 @@ __global__ __launch_bounds__(256) void k_collide_wide(const Args a) {
 				collide<Q, COLL, false>(f, feat, &bo, a, n, rhon, uxn, uyn, uzn, &wf[v]);
 				if (feat(F_UPDATE_FIELDS)) { out[0][v] = rhon; out[1][v] = uxn; out[2][v] = uyn; out[3][v] = uzn; }
 				// streaming part 1 in registers: the slot that held f[i] receives f[i+1] and vice versa (kernel.cpp:1339-1345)
-				d[0][v] = S::encode(f[0]);
+				S::template prescale<Q>(f);
+				d[0][v] = S::encode_scaled(f[0]);
 				static_for<1, Q, 2>([&](auto I) {
 					constexpr int i = I;
-					d[i][v] = S::encode(f[i+1]);
-					d[i+1][v] = S::encode(f[i]);
+					d[i][v] = S::encode_scaled(f[i+1]);
+					d[i+1][v] = S::encode_scaled(f[i]);
 				});
 			}
 		} else {
@@ -267,8 +269,9 @@ __global__ __launch_bounds__(256) void k_collide_wide(const Args a) {
 				}
 				// streaming part 1 in registers (kernel.cpp:1339-1345); an inactive cell keeps the bits that were read
 				const bool keep0 = !active[v], keep1 = !active[v+1];
+				S::template prescale<Q>(f);
 				auto put = [&](auto I, const float2v val) {
-					const typename S::raw2 e = S::encode2(val);
+					const typename S::raw2 e = S::encode2_scaled(val);
 					set_pair<typename S::raw2, V>(d[I], v, S::merge2(pair_of<typename S::raw2, V>(d[I], v), e, keep0, keep1));
 				};
 				put(std::integral_constant<int, 0>{}, f[0]);

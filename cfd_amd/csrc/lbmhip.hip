@@ -534,6 +534,23 @@ static int launch_collide_planes(lbmhip_domain* d, uint64_t t, float fx, float f
 	return 0;
 }
 
+// the kernels' own load / store conversions (lbm.cpp:561-609, kernel.cpp:858-869) applied to an array
+template <int ST> __global__ __launch_bounds__(256) void k_convert_ddfs(const void* in, void* out, const uint64_t count, const int to_storage, const int pairs) {
+	using S = Store<ST>; using raw = typename S::raw;
+	const uint64_t stride = (uint64_t)gridDim.x*blockDim.x, first = (uint64_t)blockIdx.x*blockDim.x+threadIdx.x;
+	if (!pairs) {
+		for (uint64_t i = first; i < count; i += stride) {
+			if (to_storage) static_cast<raw*>(out)[i] = S::encode(static_cast<const float*>(in)[i]);
+			else static_cast<float*>(out)[i] = S::decode(static_cast<const raw*>(in)[i]);
+		}
+	} else { // two neighbouring values at a time, the packed forms used when a lane collides two cells together; count is even
+		typedef typename S::raw2 raw2;
+		for (uint64_t i = first; 2u*i < count; i += stride) {
+			if (to_storage) static_cast<raw2*>(out)[i] = S::encode2(static_cast<const float2v*>(in)[i]);
+			else static_cast<float2v*>(out)[i] = S::decode2(static_cast<const raw2*>(in)[i]);
+		}
+	}
+}
 #define DISPATCH_Q_ST(Q_, ST_, CALL) \
 	switch (Q_) { \
 		case 9:  switch (ST_) { case ST_FP32: { constexpr int Q = 9,  ST = ST_FP32; CALL; } break; case ST_FP16S: { constexpr int Q = 9,  ST = ST_FP16S; CALL; } break; default: { constexpr int Q = 9,  ST = ST_FP16C; CALL; } break; } break; \
@@ -824,6 +841,36 @@ int lbmhip_object_sum(lbmhip_domain* d, int what, uint8_t flag_marker, const flo
 	if (e != hipSuccess) return fail("object sum failed: %s", hipGetErrorString(e));
 	sums[0] = sums[1] = sums[2] = sums[3] = 0.0;
 	for (uint32_t b = 0u; b < blocks; b++) { sums[0] += host[b].x; sums[1] += host[b].y; sums[2] += host[b].z; sums[3] += host[b].w; }
+	return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- DDF storage conversion
+int lbmhip_convert_ddfs(int device, uint32_t storage, int to_storage, int pairs, const void* in, void* out, uint64_t count) {
+	NEED(in && out, "null argument");
+	NEED(storage <= LBMHIP_FP16C, "unknown DDF storage %u", storage);
+	NEED(!pairs || count%2u == 0u, "conversion in pairs needs an even count");
+	if (count == 0u) return 0;
+	DeviceGuard g(device);
+	NEED(g.ok, "cannot select device %d", device);
+	const uint64_t raw_bytes = count*storage_bytes(storage), float_bytes = count*4u;
+	const uint64_t in_bytes = to_storage ? float_bytes : raw_bytes, out_bytes = to_storage ? raw_bytes : float_bytes;
+	void* din = nullptr; void* dout = nullptr;
+	hipError_t e = hipMalloc(&din, in_bytes);
+	if (e == hipSuccess) e = hipMalloc(&dout, out_bytes);
+	if (e == hipSuccess) e = hipMemcpy(din, in, in_bytes, hipMemcpyHostToDevice);
+	if (e == hipSuccess) {
+		const dim3 grid((uint32_t)std::min<uint64_t>((count+255u)/256u, 8192u)), block(256);
+		switch (storage) {
+			case LBMHIP_FP32: hipLaunchKernelGGL((k_convert_ddfs<ST_FP32>), grid, block, 0, nullptr, din, dout, count, to_storage, pairs); break;
+			case LBMHIP_FP16S: hipLaunchKernelGGL((k_convert_ddfs<ST_FP16S>), grid, block, 0, nullptr, din, dout, count, to_storage, pairs); break;
+			default: hipLaunchKernelGGL((k_convert_ddfs<ST_FP16C>), grid, block, 0, nullptr, din, dout, count, to_storage, pairs); break;
+		}
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipMemcpy(out, dout, out_bytes, hipMemcpyDeviceToHost);
+	if (din) (void)hipFree(din);
+	if (dout) (void)hipFree(dout);
+	if (e != hipSuccess) return fail("lbmhip_convert_ddfs failed: %s", hipGetErrorString(e));
 	return 0;
 }
 

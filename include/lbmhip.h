@@ -161,6 +161,15 @@ int lbmhip_unvoxelize_mesh(lbmhip_domain* domain, uint8_t flag, const float* bou
  * in double, so the result is reproducible and agrees with the reference to float rounding of the summation. */
 int lbmhip_object_sum(lbmhip_domain* domain, int what, uint8_t flag_marker, const float* center, const uint32_t* global_size, double* sums);
 
+/* ---- DDF storage formats: the load / store conversions of the kernels (lbm.cpp:561-609: FP32 identity, FP16S IEEE half
+ * scaled by 2^15, FP16C the custom 1-4-11 format of kernel.cpp:858-869; host-side counterparts utilities.hpp:121-144)
+ * applied to a HOST array on `device`, with the same device code the lattice kernels use.  to_storage != 0: in = count
+ * floats, out = count stored values (float for FP32, 16-bit otherwise); to_storage == 0: the reverse.  pairs != 0 converts
+ * two neighbouring values at a time with the packed instructions the kernels use when a lane collides two cells together
+ * (count must be even); the results are the same.  For hosts that prepare or inspect raw DDFs, and for checking the
+ * conversions exhaustively.  Complete when the call returns. */
+int lbmhip_convert_ddfs(int device, uint32_t storage, int to_storage, int pairs, const void* in, void* out, uint64_t count);
+
 /* ---- timing on the handle's stream (the reference only has a host clock, lbm.cpp:1481-1483) */
 int lbmhip_timer_start(lbmhip_domain* domain);
 int lbmhip_timer_stop(lbmhip_domain* domain, float* milliseconds); /* waits for the stream */

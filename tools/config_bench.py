@@ -1,6 +1,8 @@
 """Diagnostic: single-GPU stream_collide rate of the five benchmark configurations (GPU needed).  The lattices start at
 rest (the rate does not depend on the field data); solids are an extruded pillar mask uploaded plane by plane, so no
-host copy of the big lattices is ever made.  usage: python tools/config_bench.py [--sweep] [names...]   (--sweep also tries every launch geometry)"""
+host copy of the big lattices is ever made.
+usage: python tools/config_bench.py [--sweep] [--geometry=V,P,blocks_per_cu,block] [--steps=n] [names...]
+(--sweep also tries every launch geometry; --geometry fixes it and skips the library's search, for profiler passes that must see one kernel)"""
 import ctypes as C
 import sys
 
@@ -72,7 +74,7 @@ def run(name, c):
         def measure(label, warm=6):
             for _ in range(warm):
                 step(t[0]); t[0] += 1
-            n = max(10, min(400, int(4e9 / dom.N)))
+            n = STEPS or max(10, min(400, int(4e9 / dom.N)))
             ms = C.c_float()
             L.check(lib.lbmhip_timer_start(dom.h))
             for _ in range(n):
@@ -82,7 +84,10 @@ def run(name, c):
             return per, "%-26s %5dx%4dx%4d  %-22s %.3f ms/step  %7.0f MLUPs/s  %4d B/cell  %5.0f GB/s (%.1f%% of 8 TB/s)" % (
                 name, Nx, Ny, Nz, label, per, dom.N / per / 1e3, B, B * dom.N / per / 1e6, B * dom.N / per / 1e6 / 80)
 
-        per, line = measure("default", warm=100)  # covers the library's geometry search
+        if GEOMETRY:
+            for key, val in zip(("cells_per_thread", "cells_together", "blocks_per_cu", "block"), GEOMETRY):
+                L.check(lib.lbmhip_set_tuning(dom.h, key.encode(), val))
+        per, line = measure("fixed" if GEOMETRY else "default", warm=6 if GEOMETRY else 100)  # 100 launches cover the library's geometry search
         got = {}
         for key in ("tuned", "cells_per_thread", "cells_together", "blocks_per_cu", "block"):
             v = C.c_int(); L.check(lib.lbmhip_get_tuning(dom.h, key.encode(), C.byref(v))); got[key] = v.value
@@ -105,6 +110,8 @@ def run(name, c):
 
 SWEEP = "--sweep" in sys.argv or "--sweep-blocks" in sys.argv
 BLOCKS = (0, 192, 128, 64) if "--sweep-blocks" in sys.argv else (0,)
+GEOMETRY = next((tuple(int(v) for v in a.split("=")[1].split(",")) for a in sys.argv[1:] if a.startswith("--geometry=")), None)
+STEPS = next((int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--steps=")), 0)
 names = [a for a in sys.argv[1:] if not a.startswith("--")]
 for name in (names or list(CONFIGS)):
     run(name, CONFIGS[name])
