@@ -56,7 +56,7 @@ def measured_traffic(workload):
         return None
 
 
-TUNE_STEPS = 100
+TUNE_STEPS = 400
 
 
 def main():
@@ -101,7 +101,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    lbm.run(TUNE_STEPS)   # untimed: the library tries its launch geometries on the first full-lattice launches and keeps the fastest
+    # untimed: the library tries its launch geometries on the first full-lattice launches and keeps the fastest
+    tuned = C.c_int(0)
+    for _ in range(TUNE_STEPS // 20):
+        lbm.run(20)
+        check(cfd_amd.lib().lbmhip_get_tuning(lbm.ops.dom.h, b"tuned", C.byref(tuned)))
+        if tuned.value:
+            break
     lbm.run(a.warmup)
     barrier()
     lib = cfd_amd.lib()

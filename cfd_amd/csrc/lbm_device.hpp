@@ -98,6 +98,28 @@ __device__ __forceinline__ void set_(float2v& a, int k, float v) { if (k) a.y = 
 __device__ __forceinline__ float select_(const bool* m, float a, float b) { return m[0] ? a : b; }
 __device__ __forceinline__ float2v select_(const bool* m, float2v a, float2v b) { float2v r; r.x = m[0] ? a.x : b.x; r.y = m[1] ? a.y : b.y; return r; }
 template <class R> __device__ __forceinline__ R load_(const float* p) { return *reinterpret_cast<const R*>(p); } // p is aligned to sizeof(R)
+// Memory access as wave-uniform base + 32-bit byte offset of the lane: the base stays in scalar registers and the access
+// needs no 64-bit vector address arithmetic (global_load/store with an SGPR base).  Offsets are below 2^32 because a
+// lattice row is (Nx < 2^30 cells, checked when a domain is created).
+// Values travel as 1, 2, 4, 8 or 16 plain bytes (vectors of 16-bit elements as dwords).
+template <int BYTES> struct bytes_of;
+template <> struct bytes_of<1> { typedef uint8_t type; };
+template <> struct bytes_of<2> { typedef uint16_t type; };
+template <> struct bytes_of<4> { typedef uint32_t type; };
+template <> struct bytes_of<8> { typedef uint32_t type __attribute__((ext_vector_type(2))); };
+template <> struct bytes_of<16> { typedef uint32_t type __attribute__((ext_vector_type(4))); };
+template <class T, class B> __device__ __forceinline__ T ld(const B* uniform_base, const uint32_t byte_offset) {
+	typedef typename bytes_of<sizeof(T)>::type W;
+	return __builtin_bit_cast(T, *reinterpret_cast<const W*>(reinterpret_cast<const char*>(uniform_base)+byte_offset));
+}
+// The same offset as a value the optimiser cannot trace back: address arithmetic written with it is not merged with the
+// arithmetic of an earlier program section (merged, the full 64-bit vector addresses would be carried across the section
+// in registers instead of being formed by the store instruction from scalar base + offset).
+__device__ __forceinline__ uint32_t fresh(uint32_t v) { asm("" : "+v"(v)); return v; }
+template <class T, class B> __device__ __forceinline__ void st(B* uniform_base, const uint32_t byte_offset, const T value) {
+	typedef typename bytes_of<sizeof(T)>::type W;
+	*reinterpret_cast<W*>(reinterpret_cast<char*>(uniform_base)+byte_offset) = __builtin_bit_cast(W, value);
+}
 
 // c_i . (a,b,c) with zero components skipped, accumulated in x,y,z order
 template <int Q, int I, class R> __device__ __forceinline__ R cdot(R a, R b, R c) {
@@ -274,9 +296,10 @@ template <int Q, int I, class R> __device__ __forceinline__ R forcing_term(R ux,
 // f[] holds the streamed-in DDFs; on return it holds the post-collision DDFs (kernel.cpp:1497-1651).
 // FEAT is the feature mask (compile-time when the kernel is specialised, run-time otherwise); bo[] and write_fields[] have one entry per cell.
 template <int Q, int COLL, bool FIELDS_ONLY, class Feat, class R>
-__device__ __forceinline__ void collide(R* f, const Feat feat, const uint8_t* bo, const Args& a, const uint64_t n,
+__device__ __forceinline__ void collide(R* f, const Feat feat, const uint8_t* bo, const Args& a, const uint64_t row0, const uint32_t x,
                                         R& rhon, R& uxn, R& uyn, R& uzn, bool* write_fields) {
 	constexpr int W = lanes_of<R>::W;
+	const uint64_t n = row0+x; // the cell (the first of the pair); row0 is wave-uniform
 	bool eq_cell[W];
 #pragma unroll
 	for (int k = 0; k < W; k++) eq_cell[k] = feat(F_EQUILIBRIUM_BOUNDARIES) && bo[k] == TYPE_E;
@@ -289,7 +312,7 @@ __device__ __forceinline__ void collide(R* f, const Feat feat, const uint8_t* bo
 		}
 	}
 	R fxn = R(a.fx), fyn = R(a.fy), fzn = R(a.fz);
-	if (feat(F_FORCE_FIELD)) { fxn += load_<R>(a.F+n); fyn += load_<R>(a.F+a.N+n); fzn += load_<R>(a.F+2ull*a.N+n); }
+	if (feat(F_FORCE_FIELD)) { fxn += ld<R>(a.F+row0, 4u*x); fyn += ld<R>(a.F+a.N+row0, 4u*x); fzn += ld<R>(a.F+2ull*a.N+row0, 4u*x); }
 	if (feat(F_VOLUME_FORCE)) {
 		const R rho2 = div_(R(0.5f), rhon);
 		uxn = clamp_c(fma_(fxn, rho2, uxn)); uyn = clamp_c(fma_(fyn, rho2, uyn)); uzn = clamp_c(fma_(fzn, rho2, uzn));

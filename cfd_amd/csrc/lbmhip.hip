@@ -98,6 +98,7 @@ static hipError_t copy_ddfs(lbmhip_domain* d, void* host, uint64_t offset, uint6
 }
 
 static const uint32_t kObjectSumBlocks = 2048u;
+static const int kTuneReps = 3; // timed launches per candidate of the launch-geometry search
 static uint32_t q_transfers(uint32_t Q) { return Q == 9u ? 3u : Q == 27u ? 9u : 5u; }
 static uint32_t storage_bytes(uint32_t st) { return st == LBMHIP_FP32 ? 4u : 2u; }
 static bool valid_q(uint32_t Q) { return Q == 9u || Q == 15u || Q == 19u || Q == 27u; }
@@ -200,6 +201,7 @@ int lbmhip_domain_create(const lbmhip_config* c, lbmhip_domain** out) {
 	NEED(c->collision <= LBMHIP_TRT, "No LBM collision operator selected (collision=%u).", c->collision);
 	NEED(c->nu > 0.0f, c->nu == 0.0f ? "Viscosity cannot be 0." : "Viscosity cannot be negative.");
 	NEED((c->features&~63u) == 0u, "unknown feature bits 0x%x", c->features);
+	NEED(c->Nx < (1u<<30), "lattice rows of %u cells exceed the 2^30 limit", c->Nx);
 	NEED(c->Nz <= 65535u && (uint64_t)c->Nx*c->Ny < 0xFFFFFF00ull, "lattice %ux%ux%u exceeds the launch limits (Nz <= 65535, Nx*Ny < 2^32)", c->Nx, c->Ny, c->Nz);
 	for (int ax = 0; ax < 3; ax++) {
 		const uint32_t n = ax == 0 ? c->Nx : ax == 1 ? c->Ny : c->Nz, dd = ax == 0 ? c->Dx : ax == 1 ? c->Dy : c->Dz;
@@ -504,27 +506,33 @@ static int launch_collide_planes(lbmhip_domain* d, uint64_t t, float fx, float f
 	if (fields_only || user_set || !d->autotune) return launch_collide_geometry(d, a, V, P, blocks_per_cu, d->block, z0, z1, fields_only);
 	if (d->tuned) return launch_collide_geometry(d, a, d->tuned_V, d->tuned_P, d->tuned_blocks_per_cu, d->tuned_block, z0, z1, false);
 
-	// Geometry search: every full-lattice launch of the first 3*ncand steps runs one candidate between two events; all
+	// Geometry search: every full-lattice launch of the first 4*ncand steps runs one candidate between two events; all
 	// candidates compute the same bits, so the search is invisible in the results.  Lattices too small to time are left alone.
 	const uint64_t cells = (uint64_t)d->cfg.Nx*d->cfg.Ny*(z1-z0);
 	const bool searchable = d->N >= (1ull<<21) && 4u*(uint64_t)(z1-z0) >= 3u*(uint64_t)(d->cfg.Nz-2u*hz) && cells > 0u;
 	if (!searchable) return launch_collide_geometry(d, a, V, P, blocks_per_cu, 0, z0, z1, false);
 	if (d->ncand == 0) build_candidates(d);
-	if (d->tune_pending >= 0) { // collect the previous candidate's time
+	// every candidate runs kTuneReps+1 launches in a row: the first is not timed (it starts from the memory and cache state
+	// the previous candidate left behind), the others are timed one by one and their median counts
+	if (d->tune_pending >= 0) { // collect the previous launch's time
 		float ms = 0.0f;
 		HIP_TRY(hipEventSynchronize(d->ev_tune1));
 		HIP_TRY(hipEventElapsedTime(&ms, d->ev_tune0, d->ev_tune1));
-		d->cand[d->tune_pending].ms[std::min(2, (d->tune_launches-1)/d->ncand)] = ms;
+		const int rep = (d->tune_launches-1)%(kTuneReps+1);
+		if (rep > 0) d->cand[d->tune_pending].ms[rep-1] = ms;
 		d->tune_pending = -1;
-		if (d->tune_launches >= 3*d->ncand) {
+		if (d->tune_launches >= (kTuneReps+1)*d->ncand) {
 			int best = 0;
 			auto median = [&](int k) { const float* m = d->cand[k].ms; return std::max(std::min(m[0], m[1]), std::min(std::max(m[0], m[1]), m[2])); };
 			for (int k = 1; k < d->ncand; k++) if (median(k) < median(best)) best = k;
+			if (getenv("LBMHIP_TUNE_VERBOSE")) for (int k = 0; k < d->ncand; k++)
+				fprintf(stderr, "lbmhip tune: cells/lane %d together %d blocks/CU<=%d block %d: %.4f %.4f %.4f ms%s\n", d->cand[k].V, d->cand[k].P, d->cand[k].blocks_per_cu,
+				        d->cand[k].block, d->cand[k].ms[0], d->cand[k].ms[1], d->cand[k].ms[2], k == best ? "  <- kept" : "");
 			d->tuned_V = d->cand[best].V; d->tuned_P = d->cand[best].P; d->tuned_blocks_per_cu = d->cand[best].blocks_per_cu; d->tuned_block = d->cand[best].block; d->tuned = 1;
 			return launch_collide_geometry(d, a, d->tuned_V, d->tuned_P, d->tuned_blocks_per_cu, d->tuned_block, z0, z1, false);
 		}
 	}
-	const int k = d->tune_launches%d->ncand;
+	const int k = d->tune_launches/(kTuneReps+1);
 	HIP_TRY(hipEventRecord(d->ev_tune0, d->stream));
 	const int status = launch_collide_geometry(d, a, d->cand[k].V, d->cand[k].P, d->cand[k].blocks_per_cu, d->cand[k].block, z0, z1, false);
 	if (status) return status;

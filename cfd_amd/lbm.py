@@ -21,7 +21,8 @@ HALO_FI, HALO_RHO_U_FLAGS, HALO_FLAGS, HALO_F = range(4)
 BUF_SEND_P, BUF_SEND_M, BUF_RECV_P, BUF_RECV_M = range(4)
 TYPE_S, TYPE_E, TYPE_T, TYPE_F, TYPE_I, TYPE_G, TYPE_X, TYPE_Y, TYPE_MS = 1, 2, 4, 8, 16, 32, 64, 128, 3
 
-lib_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "liblbmhip.so")
+# LBMHIP_LIB names another build of the library (diagnostic: comparing two builds on the same GPU)
+lib_path = os.environ.get("LBMHIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "liblbmhip.so")
 
 
 class LbmHipError(RuntimeError):

@@ -87,7 +87,14 @@ def run(name, c):
         if GEOMETRY:
             for key, val in zip(("cells_per_thread", "cells_together", "blocks_per_cu", "block"), GEOMETRY):
                 L.check(lib.lbmhip_set_tuning(dom.h, key.encode(), val))
-        per, line = measure("fixed" if GEOMETRY else "default", warm=6 if GEOMETRY else 100)  # 100 launches cover the library's geometry search
+        if not GEOMETRY:  # let the library's geometry search finish
+            tuned = C.c_int(0)
+            for _ in range(400):
+                step(t[0]); t[0] += 1
+                L.check(lib.lbmhip_get_tuning(dom.h, b"tuned", C.byref(tuned)))
+                if tuned.value:
+                    break
+        per, line = measure("fixed" if GEOMETRY else "default", warm=6)
         got = {}
         for key in ("tuned", "cells_per_thread", "cells_together", "blocks_per_cu", "block"):
             v = C.c_int(); L.check(lib.lbmhip_get_tuning(dom.h, key.encode(), C.byref(v))); got[key] = v.value
