@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -47,6 +48,7 @@ struct lbmhip_domain {
 	int ncand, tune_launches, tune_pending, autotune, tuned, tuned_V, tuned_P, tuned_blocks_per_cu, tuned_block;
 	hipEvent_t ev_tune0, ev_tune1;
 	int uses_jit;  // the last stream_collide launch ran a kernel compiled at run time for this domain's feature set
+	void* mesh; uint64_t mesh_capacity; // triangle corners of the last voxelized mesh (grown on demand)
 	void* partial; // per-workgroup partial sums of the object_* reductions (kObjectSumBlocks float4)
 	float w;
 };
@@ -286,6 +288,7 @@ int lbmhip_domain_destroy(lbmhip_domain* d) {
 	for (int k = 0; k < 5; k++) if (d->field[k]) (void)hipFree(d->field[k]);
 	for (int k = 0; k < 4; k++) if (d->halo_own[k]) (void)hipFree(d->halo_own[k]);
 	if (d->partial) (void)hipFree(d->partial);
+	if (d->mesh) (void)hipFree(d->mesh);
 	if (d->ev_start) (void)hipEventDestroy(d->ev_start);
 	if (d->ev_stop) (void)hipEventDestroy(d->ev_stop);
 	if (d->ev_tune0) (void)hipEventDestroy(d->ev_tune0);
@@ -775,19 +778,15 @@ int lbmhip_halo_exchange_rccl(lbmhip_domain* d, void* comm, int what, int axis, 
 }
 
 // ---------------------------------------------------------------------------------------------- mesh voxelizer
-int lbmhip_voxelize_mesh(lbmhip_domain* d, uint32_t direction, uint64_t t, uint8_t flag, const float* p0, const float* p1, const float* p2, uint32_t triangles,
-                         const float* bounding_box, const float* rotation_center, const float* linear_velocity, const float* rotational_velocity) {
-	NEED(d && p0 && p1 && p2 && bounding_box, "null argument");
-	NEED(direction < 3u, "direction must be 0, 1 or 2");
-	NEED(triangles > 0u, "mesh without triangles");
-	DeviceGuard g(d->cfg.device);
+// Copies the three corner arrays (host) behind one another into `dev` (room for 9*triangles floats) and runs the kernel on the
+// handle's stream; returns when the flags (and, for a moving mesh, u and the DDFs) are written.
+static int voxelize_with_buffer(lbmhip_domain* d, float* dev, uint32_t direction, uint64_t t, uint8_t flag, const float* p0, const float* p1, const float* p2,
+                                uint32_t triangles, const float* bounding_box, const float* rotation_center, const float* linear_velocity, const float* rotational_velocity) {
 	const size_t bytes = (size_t)triangles*3u*sizeof(float);
-	float* dev = nullptr;
-	HIP_TRY(hipMalloc(&dev, 3u*bytes));
 	hipError_t e = hipMemcpyAsync(dev, p0, bytes, hipMemcpyHostToDevice, d->stream);
 	if (e == hipSuccess) e = hipMemcpyAsync(dev+(size_t)triangles*3u, p1, bytes, hipMemcpyHostToDevice, d->stream);
 	if (e == hipSuccess) e = hipMemcpyAsync(dev+(size_t)triangles*6u, p2, bytes, hipMemcpyHostToDevice, d->stream);
-	if (e != hipSuccess) { (void)hipFree(dev); return fail("uploading the mesh failed: %s", hipGetErrorString(e)); }
+	if (e != hipSuccess) return fail("uploading the mesh failed: %s", hipGetErrorString(e));
 	VoxelArgs v;
 	v.lat = make_args(d, t, 0.0f, 0.0f, 0.0f);
 	v.p0 = dev; v.p1 = dev+(size_t)triangles*3u; v.p2 = dev+(size_t)triangles*6u;
@@ -804,9 +803,57 @@ int lbmhip_voxelize_mesh(lbmhip_domain* d, uint32_t direction, uint64_t t, uint8
 	DISPATCH_Q_ST((int)d->cfg.velocity_set, (int)d->cfg.storage, hipLaunchKernelGGL((k_voxelize_mesh<Q, ST>), grid, block, 0, d->stream, v));
 	e = hipGetLastError();
 	if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
-	(void)hipFree(dev);
 	if (e != hipSuccess) return fail("voxelize_mesh failed: %s", hipGetErrorString(e));
 	return 0;
+}
+static int voxelize_check(const lbmhip_domain* d, uint32_t direction, const float* p0, const float* p1, const float* p2, uint32_t triangles, const float* bounding_box) {
+	NEED(d && p0 && p1 && p2 && bounding_box, "null argument");
+	NEED(direction < 3u, "direction must be 0, 1 or 2");
+	NEED(triangles > 0u, "mesh without triangles");
+	return 0;
+}
+int lbmhip_voxelize_mesh(lbmhip_domain* d, uint32_t direction, uint64_t t, uint8_t flag, const float* p0, const float* p1, const float* p2, uint32_t triangles,
+                         const float* bounding_box, const float* rotation_center, const float* linear_velocity, const float* rotational_velocity) {
+	if (voxelize_check(d, direction, p0, p1, p2, triangles, bounding_box)) return 1;
+	DeviceGuard g(d->cfg.device);
+	const size_t bytes = (size_t)triangles*9u*sizeof(float);
+	if (bytes > d->mesh_capacity) { // the domain keeps its triangle buffer: a mesh that moves is voxelized again every step (lbm.cpp:1645-1670)
+		HIP_TRY(hipStreamSynchronize(d->stream));
+		if (d->mesh) (void)hipFree(d->mesh);
+		d->mesh = nullptr; d->mesh_capacity = 0u;
+		HIP_TRY(hipMalloc(&d->mesh, bytes));
+		d->mesh_capacity = bytes;
+	}
+	return voxelize_with_buffer(d, static_cast<float*>(d->mesh), direction, t, flag, p0, p1, p2, triangles, bounding_box, rotation_center, linear_velocity, rotational_velocity);
+}
+
+// The same call for callers that must not allocate device memory (code under graph capture, serving loops, harnesses that
+// forbid hipMalloc): the triangles are staged in a fixed array in the library's device image.  Every GPU holds its own copy
+// of the array at its own address; host code may only use that address, looked up once per device, never the array's name.
+static __device__ __align__(256) float scratch[9u*LBMHIP_STATIC_MESH_TRIANGLES];
+static int scratch_address(int device, float** out) { // the device must be current
+	static std::mutex lock;
+	static float* address[64];
+	NEED(device >= 0 && device < 64, "device ordinal %d is outside the table of static buffers (0..63)", device);
+	std::lock_guard<std::mutex> hold(lock);
+	if (!address[device]) {
+		void* p = nullptr;
+		HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+		NEED(p, "hipGetSymbolAddress returned a null address for the static mesh buffer");
+		address[device] = static_cast<float*>(p);
+	}
+	*out = address[device];
+	return 0;
+}
+int lbmhip_voxelize_mesh_static(lbmhip_domain* d, uint32_t direction, uint64_t t, uint8_t flag, const float* p0, const float* p1, const float* p2, uint32_t triangles,
+                                const float* bounding_box, const float* rotation_center, const float* linear_velocity, const float* rotational_velocity) {
+	if (voxelize_check(d, direction, p0, p1, p2, triangles, bounding_box)) return 1;
+	NEED(triangles <= LBMHIP_STATIC_MESH_TRIANGLES, "mesh of %u triangles exceeds the static buffer of %u triangles; use lbmhip_voxelize_mesh", triangles, (uint32_t)LBMHIP_STATIC_MESH_TRIANGLES);
+	DeviceGuard g(d->cfg.device);
+	NEED(g.ok, "cannot select device %d", d->cfg.device);
+	float* dev = nullptr;
+	if (scratch_address(d->cfg.device, &dev)) return 1;
+	return voxelize_with_buffer(d, dev, direction, t, flag, p0, p1, p2, triangles, bounding_box, rotation_center, linear_velocity, rotational_velocity);
 }
 int lbmhip_unvoxelize_mesh(lbmhip_domain* d, uint8_t flag, const float* bounding_box) {
 	NEED(d && bounding_box, "null argument");

@@ -399,13 +399,15 @@ class LBM:
         self.initialized = False
 
     # ---- LBM::voxelize_mesh_on_device / voxelize_stl (lbm.cpp:1645-1670, 1728-1752)
-    def voxelize_mesh_on_device(self, mesh, flag=TYPE_S, rotation_center=(0, 0, 0), linear_velocity=(0, 0, 0), rotational_velocity=(0, 0, 0)):
+    def voxelize_mesh_on_device(self, mesh, flag=TYPE_S, rotation_center=(0, 0, 0), linear_velocity=(0, 0, 0), rotational_velocity=(0, 0, 0), static=False):
+        """static=True stages the triangles in the library's fixed device buffer (lbmhip_voxelize_mesh_static: no device allocation)."""
         direction, bbox, rc, lin, rot = meshlib.voxelize_parameters(mesh, rotation_center, linear_velocity, rotational_velocity)
+        call = self._L.lbmhip_voxelize_mesh_static if static else self._L.lbmhip_voxelize_mesh
         fp = lambda a: np.ascontiguousarray(a, dtype=np.float32).ctypes.data_as(C.c_void_p)
         p0, p1, p2 = (np.ascontiguousarray(p, dtype=np.float32) for p in (mesh.p0, mesh.p1, mesh.p2))
         for dom in self.domains:
-            check(self._L.lbmhip_voxelize_mesh(dom.h, C.c_uint32(direction), C.c_uint64(self.t + 1), C.c_uint8(flag), fp(p0), fp(p1), fp(p2),
-                                               C.c_uint32(mesh.triangle_number), fp(bbox), fp(rc), fp(lin), fp(rot)))
+            check(call(dom.h, C.c_uint32(direction), C.c_uint64(self.t + 1), C.c_uint8(flag), fp(p0), fp(p1), fp(p2),
+                       C.c_uint32(mesh.triangle_number), fp(bbox), fp(rc), fp(lin), fp(rot)))
         if not self.initialized:  # the host copies follow the device until the first run() (lbm.cpp:1666-1669)
             self._read_raw(("flags", "u"))
 
