@@ -1,18 +1,27 @@
 #!/usr/bin/env python3
 """Headline benchmark: MLUPs/s of the lattice-Boltzmann time step on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W [--config tgv|channel|q27_force] [--scaling weak|strong]
 
-Workload (the configuration the headline metric is quoted on): periodic Taylor-Green vortex, D3Q19 SRT, FP32 DDFs, 512^3 cells per GPU,
-no UPDATE_FIELDS (153 algorithmic bytes per cell and step).  With N GPUs the lattice is 512 x 512 x (512 N), split
-into N z-slabs (weak scaling); the only communication is the per-step DDF halo exchange with the two z-neighbours.
-A step = one stream_collide pass over the whole lattice (+ halo exchange).  Inputs are resident in HBM before the
-timed region.  Rank 0 prints ONE JSON line.
+N > 1 runs one rank per GPU over RCCL.  Started under torch.distributed.run (WORLD_SIZE set) it is one of those ranks;
+started plainly it launches the N ranks itself (before anything touches the GPU), forwards rank 0's JSON line and exits
+with their status.
+
+Configurations (a step = one stream_collide pass over the whole lattice + the DDF halo exchange between z-slabs):
+  tgv        periodic Taylor-Green vortex, D3Q19 SRT, 512^3 cells per GPU, weak scaling - the configuration the headline
+             metric is quoted on (153 algorithmic bytes per cell and step with FP32 DDFs)
+  channel    force-driven channel with extruded pillars (seed 42), walls in y and z, D3Q19 TRT + SUBGRID + VOLUME_FORCE,
+             512^3 cells per GPU, weak scaling
+  q27_force  the same geometry, D3Q27 FP16C + FORCE_FIELD + VOLUME_FORCE, strong scaling: a fixed global lattice
+             (2048^3, or the largest 2048 x 2048 x Nz that fits the GPUs in use) split into N z-slabs
+Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,10 +32,19 @@ sys.path.insert(0, ROOT)
 
 PUBLISHED_MLUPS = {1: 30380.0, 8: 188742.0}  # D3Q19 SRT FP32 on MI355X, reference OpenCL code (FluidX3D-master/README.md:1079, 1615)
 HBM_PEAK_GBS = 8000.0
+TUNE_STEPS = 400
+SHORT_REGION_S = 0.5
+
+CONFIGS = {
+    "tgv": dict(Q=19, collision="SRT", features=(), storage="FP32", scaling="weak", f=(0.0, 0.0, 0.0), label="taylor_green"),
+    "channel": dict(Q=19, collision="TRT", features=("VOLUME_FORCE", "SUBGRID"), storage="FP32", scaling="weak", f=(2e-4, 0.0, 0.0), label="channel_pillars"),
+    "q27_force": dict(Q=27, collision="SRT", features=("FORCE_FIELD", "VOLUME_FORCE"), storage="FP16C", scaling="strong", f=(1e-5, 0.0, 0.0),
+                      label="channel_pillars", lattice=(2048, 2048, 2048)),
+}
 
 
 def cpu_baseline(threads):
-    """The same workload on the host cores: the reference's own kernels compiled for the CPU (oracle/_ref) when that
+    """The headline workload on the host cores: the reference's own kernels compiled for the CPU (oracle/_ref) when that
     library is present, else the scalar C restatement.  Bounded sample: a 256^3 (reference) or 128^3 (port) lattice."""
     from oracle import harness as H
     from cfd_amd import setups
@@ -40,23 +58,74 @@ def cpu_baseline(threads):
     setups.taylor_green(lbm)
     lbm.initialize()
     t0 = time.time(); lbm.run(1, threads=cores); first = time.time() - t0
-    steps = int(max(2, min(400, 15.0 / max(first, 1e-3))))
+    steps = int(max(2, min(400, 12.0 / max(first, 1e-3))))
     t0 = time.time(); lbm.run(steps, threads=cores); dt = time.time() - t0
     return {"value": round(n ** 3 * steps / dt / 1e6, 2), "unit": "MLUPs/s", "cores": cores, "kind": kind,
             "sample": "taylor_green %d^3 D3Q19 SRT FP32, %d steps in %.1f s" % (n, steps, dt)}
 
 
+def cpu_baseline_cavity(threads):
+    """Second reported baseline: the lid-driven cavity the reference runs on a CPU device (128^3, D3Q19 SRT FP32,
+    MOVING_BOUNDARIES, setup.cpp.bak:236-249), a bounded number of its 1000 steps."""
+    from oracle import harness as H
+    from cfd_amd import setups
+    tag = "long_cavity128_fp32"
+    if not H.RefEngine.available(tag):
+        return None
+    lbm = H.OracleLBM((128, 128, 128), 0.0126, features=("MOVING_BOUNDARIES",), engine_factory=lambda local, D: H.RefEngine(tag))
+    setups.lid_cavity(lbm)
+    lbm.initialize()
+    t0 = time.time(); lbm.run(5, threads=threads); first = (time.time() - t0) / 5
+    steps = int(max(10, min(1000, 10.0 / max(first, 1e-4))))
+    t0 = time.time(); lbm.run(steps, threads=threads); dt = time.time() - t0
+    return {"value": round(128 ** 3 * steps / dt / 1e6, 2), "unit": "MLUPs/s", "cores": threads, "kind": "reference",
+            "sample": "lid_cavity 128^3 D3Q19 SRT FP32 MOVING_BOUNDARIES, %d of 1000 steps in %.1f s" % (steps, dt)}
+
+
 def measured_traffic(workload):
-    """HBM bytes per stream_collide launch from the committed rocprofv3 PMC passes of this workload (or None)."""
+    """HBM bytes per stream_collide launch from the committed rocprofv3 PMC passes of this workload, with the profile they
+    come from (None, None when there is no such profile): the counters are not read in this run."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get(workload)
+            table = json.load(f)
     except (OSError, ValueError):
-        return None
+        return None, None
+    entry = table.get(workload)
+    if isinstance(entry, dict):
+        return entry.get("bytes_per_launch"), entry.get("source")
+    return entry, ("profiles/traffic.json" if entry is not None else None)
 
 
-TUNE_STEPS = 400
+def free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def launch_ranks(n):
+    """Start the N ranks as children of this process, which has not touched the GPU, and exit with their status."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def choose_lattice(a, cfg, world, lib, device):
+    """Global lattice and whether it had to be reduced to fit.  Weak: `size`^3 cells per GPU stacked along z.  Strong: the
+    configured global lattice, its z extent cut down to what the GPUs in use can hold."""
+    if a.lattice:
+        return tuple(int(v) for v in a.lattice.split(",")), False
+    if a.scaling == "weak":
+        return (a.size, a.size, a.size * world), False
+    Nx, Ny, Nz = cfg.get("lattice") or (a.size, a.size, a.size)
+    free, total = C.c_uint64(), C.c_uint64()
+    from cfd_amd.lbm import check, STORAGE, feature_mask
+    check(lib.lbmhip_device_memory(device, C.byref(free), C.byref(total)))
+    per_cell = lib.lbmhip_bytes_per_cell_device(cfg["Q"], STORAGE[a.storage], feature_mask(cfg["features"]))
+    planes = int(0.92 * free.value / (per_cell * Nx * Ny)) - 2   # per GPU, besides the two halo planes
+    fit = max(64, (planes // 64) * 64) * world
+    return (Nx, Ny, min(Nz, fit)), fit < Nz
 
 
 def main():
@@ -64,25 +133,33 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--size", type=int, default=512, help="cells per axis and GPU")
-    ap.add_argument("--storage", default="FP32", choices=["FP32", "FP16S", "FP16C"])
+    ap.add_argument("--config", default="tgv", choices=sorted(CONFIGS))
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"], help="default: the configuration's own (tgv, channel: weak; q27_force: strong)")
+    ap.add_argument("--size", type=int, default=512, help="weak scaling: cells per axis and GPU")
+    ap.add_argument("--lattice", default=None, help="global lattice Nx,Ny,Nz (overrides --size and the configuration's own)")
+    ap.add_argument("--storage", default=None, choices=["FP32", "FP16S", "FP16C"], help="DDF storage (default: the configuration's own)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse several ranks on one GPU)")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a.gpus))
 
     import torch
     import torch.distributed as dist
     import cfd_amd
     from cfd_amd import setups
     from cfd_amd.distributed import DistributedLBM
-    from cfd_amd.lbm import check
+    from cfd_amd.lbm import check, STORAGE, feature_mask
 
+    cfg = CONFIGS[a.config]
+    a.storage = a.storage or cfg["storage"]
+    a.scaling = a.scaling or cfg["scaling"]
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d; launch N>1 through torch.distributed.run" % (a.gpus, world))
+        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d" % (a.gpus, world))
     device = local_rank % torch.cuda.device_count()  # ranks share a GPU only in a gloo rehearsal
     torch.cuda.set_device(device)
     if world > 1:
@@ -90,10 +167,22 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
         else:
             dist.init_process_group(a.backend)
+    lib = cfd_amd.lib()
 
-    n = a.size
-    lbm = DistributedLBM((n, n, n * world), 0.01, Q=19, storage=a.storage, collision="SRT", rank=rank, world=world, overlap=not a.no_overlap)
-    setups.taylor_green(lbm)
+    N, reduced = choose_lattice(a, cfg, world, lib, device)
+    if world > 1:  # every rank must run the same lattice: rank 0 decides
+        box = [N, reduced]
+        dist.broadcast_object_list(box, src=0)
+        N, reduced = tuple(box[0]), box[1]
+    lean = a.config != "tgv"  # slabs of up to 10^9 cells: no host copy of the fields, flags go up plane by plane
+    lbm = DistributedLBM(N, 0.01, Q=cfg["Q"], storage=a.storage, collision=cfg["collision"], features=cfg["features"], f=cfg["f"],
+                         rank=rank, world=world, overlap=not a.no_overlap, host_fields=not lean)
+    N = lbm.N
+    if lean:
+        mask = setups.obstacle_mask(N[0], N[1], seed=42)
+        lbm.fill_planes(lambda z: {"flags": setups.channel_flag_plane(N[0], N[1], N[2], z, 42, mask)})
+    else:
+        setups.taylor_green(lbm)
     lbm.initialize()
 
     def barrier():
@@ -105,12 +194,11 @@ def main():
     tuned = C.c_int(0)
     for _ in range(TUNE_STEPS // 20):
         lbm.run(20)
-        check(cfd_amd.lib().lbmhip_get_tuning(lbm.ops.dom.h, b"tuned", C.byref(tuned)))
+        check(lib.lbmhip_get_tuning(lbm.ops.dom.h, b"tuned", C.byref(tuned)))
         if tuned.value:
             break
     lbm.run(a.warmup)
     barrier()
-    lib = cfd_amd.lib()
     ms_events = C.c_float()
     t0 = time.perf_counter()
     check(lib.lbmhip_timer_start(lbm.ops.dom.h))          # HIP events on the stream the kernels are launched on
@@ -118,31 +206,58 @@ def main():
         lbm.do_time_step()
     check(lib.lbmhip_timer_stop(lbm.ops.dom.h, C.byref(ms_events)))
     barrier()
-    seconds = time.perf_counter() - t0
+    own_seconds = time.perf_counter() - t0
+    seconds, per_rank = own_seconds, [own_seconds]
     if world > 1:
-        t = torch.tensor([seconds], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        seconds = float(t.item())
+        t = torch.tensor([own_seconds], dtype=torch.float64, device="cuda")
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        per_rank = [float(v.item()) for v in every]
+        seconds = max(per_rank)
 
-    cells_global = n * n * n * world
+    cells_global = N[0] * N[1] * N[2]
+    cells_rank = N[0] * N[1] * (N[2] // world)
     value = cells_global * a.steps / seconds / 1e6
-    B = cfd_amd.lib().lbmhip_bandwidth_bytes_per_cell(19, cfd_amd.STORAGE[a.storage], 0)
+    mask_bits = feature_mask(cfg["features"])
+    B = lib.lbmhip_bandwidth_bytes_per_cell(cfg["Q"], STORAGE[a.storage], mask_bits)
     if rank == 0:
-        workload = "taylor_green_%d^3_per_gpu_d3q19_srt_%s" % (n, a.storage.lower())
-        kernel_ms = ms_events.value / a.steps               # one rank's launches per step (N=1: exactly one stream_collide launch)
-        achieved = B * n ** 3 / (kernel_ms * 1e-3) / 1e9
+        geometry = {}
+        for key in ("tuned", "cells_per_thread", "cells_together", "blocks_per_cu", "block", "jit"):
+            v = C.c_int(); check(lib.lbmhip_get_tuning(lbm.ops.dom.h, key.encode(), C.byref(v))); geometry[key] = v.value
+        per_gpu = "%dx%dx%d" % (N[0], N[1], N[2] // world)
+        if a.config == "tgv" and N[0] == N[1] == N[2] // world:
+            workload = "taylor_green_%d^3_per_gpu_d3q19_srt_%s" % (N[0], a.storage.lower())
+        else:
+            workload = "%s_%s_per_gpu_d3q%d_%s_%s%s" % (cfg["label"], per_gpu, cfg["Q"], cfg["collision"].lower(), a.storage.lower(),
+                                                         "".join("_" + f.lower() for f in cfg["features"]))
+        kernel_ms = ms_events.value / a.steps               # this rank's launches per step (N=1: exactly one stream_collide launch)
+        achieved = B * cells_rank / (kernel_ms * 1e-3) / 1e9
+        traffic, traffic_source = measured_traffic(workload) if world == 1 else (None, None)
+        headline = a.config == "tgv" and a.storage == "FP32" and N[0] == N[1] == 512 and N[2] == 512 * world
         out = {
             "metric": "MLUPs/s", "value": round(value, 1), "unit": "MLUPs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(seconds / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": round(value / PUBLISHED_MLUPS[world], 4) if (world in PUBLISHED_MLUPS and a.storage == "FP32" and n == 512) else None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload, "lattice": [n, n, n * world], "velocity_set": "D3Q19", "collision": "SRT", "ddf_storage": a.storage,
-                       "decomposition": "z-slabs x%d" % world, "bytes_per_cell_step": B, "halo_overlap": bool(lbm.overlap)},
+            "ms_per_step": round(seconds / a.steps * 1e3, 4), "higher_is_better": True, "scaling": a.scaling,
+            "vs_baseline": round(value / PUBLISHED_MLUPS[world], 4) if (headline and world in PUBLISHED_MLUPS) else None,
+            "dtype": "f32" if a.storage == "FP32" else "f32 arithmetic, %s DDF storage" % a.storage.lower(), "data": "synthetic",
+            "config": {"workload": workload, "lattice": list(N), "velocity_set": "D3Q%d" % cfg["Q"], "collision": cfg["collision"], "extensions": list(cfg["features"]),
+                       "ddf_storage": a.storage, "decomposition": "z-slabs x%d" % world, "bytes_per_cell_step": B, "halo_overlap": bool(lbm.overlap),
+                       "backend": ("rccl" if a.backend == "nccl" else a.backend) if world > 1 else None, "lattice_reduced_to_fit": bool(reduced),
+                       "launch_geometry": geometry, "tuning_steps_untimed": "up to %d, until the geometry search finished" % TUNE_STEPS},
+            "timed_region_s": round(seconds, 4),
+            "per_rank_mlups": [round(cells_rank * a.steps / s / 1e6, 1) for s in per_rank],
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": measured_traffic(workload), "kernel": "stream_collide", "kernel_ms": round(kernel_ms, 4)},
+                         "traffic": traffic, "traffic_source": traffic_source, "kernel": "stream_collide", "kernel_ms": round(kernel_ms, 4)},
         }
+        if seconds < SHORT_REGION_S:
+            out["short_timed_region"] = True
+            print("bench.py: the timed region lasted %.3f s; --steps %d or more gives at least %.1f s" % (
+                seconds, int(a.steps * SHORT_REGION_S / seconds) + 1, SHORT_REGION_S), file=sys.stderr)
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(min(16, os.cpu_count() or 1))
+            threads = min(16, os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(threads)
+            cavity = cpu_baseline_cavity(threads)
+            if cavity:
+                out["cpu_baseline_cavity128"] = cavity
         print(json.dumps(out), flush=True)
     lbm.close()
     if world > 1:

@@ -124,7 +124,8 @@ static Args make_args(const lbmhip_domain* d, uint64_t t, float fx, float fy, fl
 	return a;
 }
 
-// RCCL entry points, resolved at first use: from the running process (the caller's RCCL), else from librccl.so
+// RCCL entry points, resolved at first use: from the library LBMHIP_RCCL_LIB names, else from the running process (the
+// caller's RCCL), else from librccl.so
 namespace {
 typedef int (*rccl_group_fn)(void);
 typedef int (*rccl_p2p_fn)(void*, size_t, int, int, void*, hipStream_t); // ncclSend / ncclRecv (the send buffer is const in RCCL's prototype)
@@ -134,7 +135,8 @@ const RcclApi& rccl_api() {
 	static const RcclApi api = []() {
 		RcclApi a = {};
 		void* h = RTLD_DEFAULT;
-		if (!dlsym(h, "ncclSend")) h = dlopen("librccl.so.1", RTLD_NOW|RTLD_GLOBAL);
+		if (const char* path = getenv("LBMHIP_RCCL_LIB")) h = dlopen(path, RTLD_NOW|RTLD_LOCAL); // a particular build of the library
+		else if (!dlsym(h, "ncclSend")) h = dlopen("librccl.so.1", RTLD_NOW|RTLD_GLOBAL);
 		if (!h) h = dlopen("librccl.so", RTLD_NOW|RTLD_GLOBAL);
 		if (!h) return a;
 		a.group_start = (rccl_group_fn)dlsym(h, "ncclGroupStart"); a.group_end = (rccl_group_fn)dlsym(h, "ncclGroupEnd");

@@ -36,6 +36,7 @@ class SlabOps:
     local = (0, 0, 0)          # local lattice size including the two z halo planes
     buffers = None             # dict send_p, send_m, recv_p, recv_m -> 1-D uint8 torch tensors
     def upload(self, rho, u, flags, F): raise NotImplementedError
+    def upload_plane(self, name, z_local, a): raise NotImplementedError
     def download(self, names): raise NotImplementedError
     def initialize(self): raise NotImplementedError
     def collide_planes(self, t, f, z0, z1): raise NotImplementedError
@@ -84,6 +85,18 @@ class HipSlabOps(SlabOps):
         d.upload(L.FIELD_RHO, d.rho); d.upload(L.FIELD_U, d.u); d.upload(L.FIELD_FLAGS, d.flags)
         if self.has_F:
             d.F[...] = F.ravel(); d.upload(L.FIELD_F, d.F)
+
+    def upload_plane(self, name, z_local, a):
+        """One lattice plane ([y, x]; u and F: [3, y, x]) into the slab, without a host copy of the whole slab."""
+        d = self.dom
+        Lx, Ly, _ = self.local
+        field, item = {"rho": (L.FIELD_RHO, 4), "u": (L.FIELD_U, 4), "flags": (L.FIELD_FLAGS, 1), "F": (L.FIELD_F, 4)}[name]
+        a = np.ascontiguousarray(a, dtype=np.uint8 if name == "flags" else np.float32)
+        if name in ("u", "F"):
+            for c in range(3):
+                d.upload(field, a[c], offset=(c * d.N + z_local * Lx * Ly) * item)
+        else:
+            d.upload(field, a, offset=z_local * Lx * Ly * item)
 
     def download(self, names):
         d = self.dom
@@ -148,9 +161,11 @@ class DistributedLBM:
 
     Host fields rho/u/flags(/F) cover the rank's own planes only ([z_local, y, x]; `origin` is their global offset),
     so setups written against N/origin/rho.shape fill them without materialising the global lattice.
+    host_fields=False keeps no host copy at all (slabs of 10^9 cells): the slab starts as the engine creates it (rho = 1,
+    everything else 0), fill_planes() writes the planes that differ, and read_from_device() is not available.
     """
 
-    def __init__(self, N, nu, Q=19, storage="FP32", collision="SRT", features=(), f=(0.0, 0.0, 0.0), rank=None, world=None, ops_factory=None, overlap=True, group=None):
+    def __init__(self, N, nu, Q=19, storage="FP32", collision="SRT", features=(), f=(0.0, 0.0, 0.0), rank=None, world=None, ops_factory=None, overlap=True, group=None, host_fields=True):
         self.group = group
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
@@ -167,11 +182,14 @@ class DistributedLBM:
             ops_factory = lambda: HipSlabOps(self.local, self.world, Q, storage, collision, features, nu, self.origin[2] - self.hz, dev)
         self.ops = ops_factory()
         Nx, Ny, _ = self.N
-        self.rho = np.ones((self.nz, Ny, Nx), dtype=np.float32)
-        self.u = np.zeros((3, self.nz, Ny, Nx), dtype=np.float32)
-        self.flags = np.zeros((self.nz, Ny, Nx), dtype=np.uint8)
         self.has_F = "FORCE_FIELD" in features
-        self.F = np.zeros((3, self.nz, Ny, Nx), dtype=np.float32) if self.has_F else None
+        self.host_fields = bool(host_fields)
+        self.rho = self.u = self.flags = self.F = None
+        if self.host_fields:
+            self.rho = np.ones((self.nz, Ny, Nx), dtype=np.float32)
+            self.u = np.zeros((3, self.nz, Ny, Nx), dtype=np.float32)
+            self.flags = np.zeros((self.nz, Ny, Nx), dtype=np.uint8)
+            self.F = np.zeros((3, self.nz, Ny, Nx), dtype=np.float32) if self.has_F else None
         self.update_fields_ext = "UPDATE_FIELDS" in features
         self.t = 0
         self.initialized = False
@@ -225,16 +243,17 @@ class DistributedLBM:
         with self.ops.scope():
             self._initialize()
 
+    def fill_planes(self, plane):
+        """plane(z_global) -> {"flags": [y, x], "rho": [y, x], "u": [3, y, x], "F": [3, y, x]} (any subset, or None) for every
+        plane this rank owns, written straight into the slab; the halo planes follow from the exchange in initialize()."""
+        for k in range(self.nz):
+            got = plane(self.origin[2] + k) or {}
+            for name, a in got.items():
+                self.ops.upload_plane(name, k + self.hz, a)
+
     def _initialize(self):
-        Lx, Ly, Lz = self.local
-        hz = self.hz
-        rho = np.ones((Lz, Ly, Lx), dtype=np.float32); rho[hz:Lz - hz] = self.rho
-        u = np.zeros((3, Lz, Ly, Lx), dtype=np.float32); u[:, hz:Lz - hz] = self.u
-        flags = np.zeros((Lz, Ly, Lx), dtype=np.uint8); flags[hz:Lz - hz] = self.flags
-        F = None
-        if self.has_F:
-            F = np.zeros((3, Lz, Ly, Lx), dtype=np.float32); F[:, hz:Lz - hz] = self.F
-        self.ops.upload(rho, u, flags, F)
+        if self.host_fields:
+            self._upload_host_fields()
         if self.has_F:
             self._communicate("F")
         self.t = 1
@@ -246,6 +265,17 @@ class DistributedLBM:
         self.t = 0
         self.initialized = True
         self.t_last_update_fields = 0 if self.update_fields_ext else None
+
+    def _upload_host_fields(self):
+        Lx, Ly, Lz = self.local
+        hz = self.hz
+        rho = np.ones((Lz, Ly, Lx), dtype=np.float32); rho[hz:Lz - hz] = self.rho
+        u = np.zeros((3, Lz, Ly, Lx), dtype=np.float32); u[:, hz:Lz - hz] = self.u
+        flags = np.zeros((Lz, Ly, Lx), dtype=np.uint8); flags[hz:Lz - hz] = self.flags
+        F = None
+        if self.has_F:
+            F = np.zeros((3, Lz, Ly, Lx), dtype=np.float32); F[:, hz:Lz - hz] = self.F
+        self.ops.upload(rho, u, flags, F)
 
     # ---- LBM::do_time_step (lbm.cpp:1411-1459)
     def do_time_step(self):
@@ -289,6 +319,8 @@ class DistributedLBM:
         self.ops.sync()
 
     def read_from_device(self):
+        if not self.host_fields:
+            raise RuntimeError("this DistributedLBM keeps no host fields (host_fields=False)")
         if self.initialized:
             self.update_fields()
         Lx, Ly, Lz = self.local

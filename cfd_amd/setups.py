@@ -76,17 +76,26 @@ def obstacle_mask(Nx, Ny, seed=42, n_pillars=12):
     return mask
 
 
+def channel_flag_plane(Nx, Ny, Nz, z, seed=42, mask=None):
+    """Flags of lattice plane z of the channel below ([y, x]): pillars and y walls, the first and last plane all solid."""
+    if z == 0 or z == Nz - 1:
+        return np.full((Ny, Nx), TYPE_S, dtype=np.uint8)
+    plane = (obstacle_mask(Nx, Ny, seed) if mask is None else mask).astype(np.uint8) * np.uint8(TYPE_S)
+    plane[0] = plane[-1] = TYPE_S
+    return plane
+
+
 def channel(lbm, seed=42, u0=0.0):
     """Force-driven channel, periodic in x, solid walls in y and z, plus an obstacle mask extruded along z.
     Needs VOLUME_FORCE (the force comes from the LBM constructor)."""
     Nx, Ny, Nz = lbm.N
-    x, y, z = _grid(lbm)
+    _, _, za = _axes(lbm)
     lbm.rho[...] = 1.0
     lbm.u[...] = 0.0
     lbm.u[0][...] = np.float32(u0)
-    wall = (y == 0) | (y == Ny - 1) | (z == 0) | (z == Nz - 1)
-    wall |= obstacle_mask(Nx, Ny, seed)[None, :, :]
-    lbm.flags[...] = np.where(wall, TYPE_S, 0).astype(np.uint8)
+    mask = obstacle_mask(Nx, Ny, seed)
+    for k, z in enumerate(za):
+        lbm.flags[k] = channel_flag_plane(Nx, Ny, Nz, int(z), seed, mask)
 
 
 def inflow_box(lbm, u_in=0.075, radius_frac=0.15):

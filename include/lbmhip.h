@@ -135,7 +135,8 @@ int lbmhip_halo_exchange_local(lbmhip_domain** domains, uint32_t count, int what
  * receives RECV_M from rank_minus and RECV_P from rank_plus, as one RCCL send/recv group on the handle's stream (ordered
  * after pack, before unpack; nothing blocks the host).  communicator is the caller's ncclComm_t for this GPU; the RCCL
  * entry points are looked up in the process at the first call (the caller that created the communicator has them loaded),
- * so the library itself does not link RCCL.  rank_minus == rank_plus (two ranks, or one rank that is its own neighbour) works. */
+ * so the library itself does not link RCCL; the environment variable LBMHIP_RCCL_LIB names a particular library file instead.
+ * rank_minus == rank_plus (two ranks, or one rank that is its own neighbour) works. */
 int lbmhip_halo_exchange_rccl(lbmhip_domain* domain, void* communicator, int what, int axis, int rank_minus, int rank_plus);
 
 /* ---- mesh voxelizer: LBM_Domain::voxelize_mesh_on_device / enqueue_unvoxelize_mesh_on_device (lbm.cpp:344-422) and the

@@ -29,6 +29,12 @@ class OracleSlabOps(SlabOps):
         if self.F is not None:
             self.F[...] = F.ravel()
 
+    def upload_plane(self, name, z_local, a):
+        Lx, Ly, Lz = self.local
+        field = getattr(self, name)
+        comps = 3 if name in ("u", "F") else 1
+        field.reshape(comps, Lz, Ly, Lx)[:, z_local] = np.asarray(a).reshape(comps, Ly, Lx)
+
     def download(self, names):
         return {k: getattr(self, k) for k in names}
 

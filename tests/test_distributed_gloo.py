@@ -33,6 +33,17 @@ def _worker(rank, world, port, kw, setup_name, steps, overlap, out_dir):
         N = kw.pop("N")
         local = decomposition.local_size(decomposition.rounded_size(N, (1, 1, world)), (1, 1, world))
         engine = lambda: OracleSlabOps(local, world, kw.get("Q", 19), kw.get("storage", "FP32"), kw.get("collision", "SRT"), kw.get("features", ()), kw["nu"])
+        if setup_name == "channel_planes":  # no host copy of the fields: flags go into the slab plane by plane
+            lbm = DistributedLBM(N, rank=rank, world=world, overlap=overlap, ops_factory=engine, host_fields=False, **kw)
+            G = lbm.N
+            lbm.fill_planes(lambda z: {"flags": setups.channel_flag_plane(G[0], G[1], G[2], z)})
+            lbm.run(steps)
+            lbm.update_fields()
+            Lx, Ly, Lz = lbm.local
+            got = lbm.ops.download(("rho", "u", "flags"))
+            np.savez(os.path.join(out_dir, "rank%d.npz" % rank), rho=got["rho"].reshape(Lz, Ly, Lx)[1:-1], u=got["u"].reshape(3, Lz, Ly, Lx)[:, 1:-1],
+                     flags=got["flags"].reshape(Lz, Ly, Lx)[1:-1])
+            return
         lbm = DistributedLBM(N, rank=rank, world=world, overlap=overlap, ops_factory=engine, **kw)
         getattr(setups, setup_name)(lbm)
         lbm.run(steps)
@@ -42,14 +53,14 @@ def _worker(rank, world, port, kw, setup_name, steps, overlap, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,overlap", [(2, True), (2, False), (3, True)])
-def test_slab_exchange_matches_single_process(tmp_path, world, overlap):
+@pytest.mark.parametrize("world,overlap,setup", [(2, True, "channel"), (2, False, "channel"), (3, True, "channel"), (2, True, "channel_planes")])
+def test_slab_exchange_matches_single_process(tmp_path, world, overlap, setup):
     sys.path.insert(0, ROOT)
     from cfd_amd import setups
     from oracle import harness as H
     kw = dict(N=(16, 12, 12 * world), nu=0.02, Q=19, storage="FP32", collision="SRT", features=("VOLUME_FORCE", "SUBGRID"), f=(1e-4, 0.0, 0.0))
     steps = 12
-    mp.spawn(_worker, args=(world, _free_port(), kw, "channel", steps, overlap, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), kw, setup, steps, overlap, str(tmp_path)), nprocs=world, join=True)
     ref = H.OracleLBM(kw["N"], kw["nu"], D=(1, 1, world), Q=19, features=kw["features"], f=kw["f"])
     setups.channel(ref)
     ref.run(steps)
@@ -61,3 +72,82 @@ def test_slab_exchange_matches_single_process(tmp_path, world, overlap):
         assert np.array_equal(got["flags"], ref.flags[sl])
         assert np.array_equal(got["rho"].view(np.uint32), ref.rho[sl].view(np.uint32))
         assert np.array_equal(got["u"].view(np.uint32), ref.u[:, sl].view(np.uint32))
+
+
+# ---- which buffer meets which: the message pairing of the exchange for 2, 3 and 8 ranks, without any process group
+class _FakeDist:
+    """Stands in for torch.distributed inside cfd_amd.distributed: records the point-to-point operations every rank issues.
+    deliver() then moves the data the way the two real backends match messages: RCCL pairs the k-th send from a to b with
+    the k-th receive b posts for a (tags are ignored); gloo pairs by (source, tag)."""
+
+    class P2POp:
+        def __init__(self, op, tensor, peer, group=None, tag=0):
+            self.op, self.tensor, self.peer, self.tag = op, tensor, peer, tag
+
+    class _Done:
+        def wait(self):
+            pass
+
+    isend, irecv = "isend", "irecv"
+
+    def __init__(self):
+        self.rank = None
+        self.posted = []  # (rank, op, tensor, peer, tag) in issue order
+
+    def get_backend(self, group=None):
+        return "fake"
+
+    def batch_isend_irecv(self, ops):
+        for o in ops:
+            self.posted.append((self.rank, o.op, o.tensor, o.peer, o.tag))
+        return [self._Done() for _ in ops]
+
+    def deliver(self, by_tag):
+        sends = [p for p in self.posted if p[1] == "isend"]
+        recvs = [p for p in self.posted if p[1] == "irecv"]
+        used = set()
+        for dst, _, rbuf, src, rtag in recvs:
+            for k, (s_rank, _, sbuf, s_peer, stag) in enumerate(sends):
+                if k in used or s_rank != src or s_peer != dst or (by_tag and stag != rtag):
+                    continue
+                used.add(k)
+                assert sbuf.numel() == rbuf.numel()
+                rbuf.copy_(sbuf)
+                break
+            else:
+                raise AssertionError("receive of rank %d from %d (tag %d) has no matching send" % (dst, src, rtag))
+        assert len(used) == len(sends), "a send was never received"
+
+
+class _BufferOps:
+    local = (4, 3, 6)
+
+    def __init__(self, rank):
+        # every byte names its origin: rank in the low bits, face in bit 6 (+ face) or bit 7 (- face)
+        mk = lambda v: torch.full((64,), v, dtype=torch.uint8)
+        self.buffers = {"send_p": mk(0x40 | rank), "send_m": mk(0x80 | rank), "recv_p": mk(0xFF), "recv_m": mk(0xFF)}
+
+
+@pytest.mark.parametrize("by_tag", [False, True])
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_exchange_pairs_plus_faces_with_minus_halos(monkeypatch, world, by_tag):
+    """lbm.cpp:2129-2136, 2162-2181: the + face of slab d becomes the - halo of slab d+1 and the - face of slab d+1 the
+    + halo of slab d, with periodic wrap; with two ranks both messages of a rank go to the same peer."""
+    sys.path.insert(0, ROOT)
+    import cfd_amd.distributed as DD
+    fake = _FakeDist()
+    monkeypatch.setattr(DD, "dist", fake)
+    ranks = []
+    for r in range(world):
+        lbm = DD.DistributedLBM((4, 3, 4 * world), 0.02, rank=r, world=world, ops_factory=lambda r=r: _BufferOps(r), host_fields=False)
+        ranks.append(lbm)
+    for r, lbm in enumerate(ranks):
+        fake.rank = r
+        lbm._exchange(48)  # a message shorter than the buffers: only the first 48 bytes travel
+    fake.deliver(by_tag)
+    for r, lbm in enumerate(ranks):
+        b = lbm.ops.buffers
+        prev, nxt = (r - 1) % world, (r + 1) % world
+        assert (b["recv_m"][:48] == (0x40 | prev)).all(), "the - halo must hold the + face of the previous slab"
+        assert (b["recv_p"][:48] == (0x80 | nxt)).all(), "the + halo must hold the - face of the next slab"
+        assert (b["recv_m"][48:] == 0xFF).all() and (b["recv_p"][48:] == 0xFF).all()

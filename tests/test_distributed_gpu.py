@@ -209,3 +209,32 @@ def test_rccl_entry_point_of_the_abi(gpu, tmp_path, overlap):
     assert np.array_equal(got["rho"].view(np.uint32), got["rho0"].view(np.uint32))
     assert np.array_equal(got["u"].view(np.uint32), got["u0"].view(np.uint32))
     assert float(np.abs(got["u"]).max()) > 1e-4
+
+
+def _script(args, timeout=600):
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable] + args, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+    assert r.returncode == 0, "%s failed:\n%s\n%s" % (" ".join(args), r.stdout[-2000:], r.stderr[-4000:])
+    return r.stdout
+
+
+def test_rccl_call_order_pairs_faces_and_halos_for_2_3_4_ranks(gpu):
+    """lbmhip_halo_exchange_rccl for several ranks with distinct peers (and with one peer on both sides, world 2): the slabs
+    live on this GPU, the RCCL entry points are stand-ins that deliver messages in RCCL's matching order."""
+    out = _script([os.path.join(ROOT, "tests", "rccl_order_check.py")])
+    assert "rccl call order ok" in out
+
+
+@pytest.mark.parametrize("extra", [[], ["--config", "channel"], ["--config", "q27_force", "--lattice", "96,64,64"]])
+def test_bench_launches_its_own_ranks(gpu, extra):
+    """`python bench.py --gpus 2` started plainly (no torch.distributed.run around it) runs two ranks and prints one JSON line.
+    Both ranks share this GPU, so the transport is gloo; the driver's multi-GPU runs use the default, RCCL."""
+    import json
+    out = _script([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--size", "64", "--steps", "30", "--warmup", "5", "--no-cpu-baseline"] + extra)
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["value"] > 0 and len(r["per_rank_mlups"]) == 2
+    assert r["config"]["decomposition"] == "z-slabs x2" and r["config"]["launch_geometry"]["cells_per_thread"] >= 0
+    assert r["roofline"]["frac"] > 0
