@@ -19,7 +19,13 @@ hipError_t launch_collide_wide(const Args& a, dim3 grid, dim3 block, uint32_t ld
 	return hipGetLastError();
 }
 
-// FEAT < 0 selects the instance that reads the feature mask at run time; FO = update_fields (always run-time features, V=1)
+template <int Q, int ST, int V>
+hipError_t launch_fields_wide(const Args& a, dim3 grid, dim3 block, uint32_t lds_bytes, hipStream_t stream) { // update_fields, V cells per lane
+	hipLaunchKernelGGL((k_collide_wide<Q, ST, COLL_SRT, -1, V, 1, true>), grid, block, lds_bytes, stream, a);
+	return hipGetLastError();
+}
+
+// FEAT < 0 selects the instance that reads the feature mask at run time; FO = update_fields (always run-time features)
 // V = cells per lane; P = 2 selects the instance that collides two cells at a time in packed arithmetic (V = 2 or 4 only)
 template <int Q, int ST, int COLL, int FEAT> collide_launch_fn pick_v(int V, int P) {
 	switch (V) {
@@ -42,7 +48,7 @@ collide_launch_fn select_collide_small(int Q, int ST, int COLL, int FEAT, int V,
 #define LBM_SPECIALISE(Q, ST, MASK) \
 	if (FEAT == (MASK)) return COLL == COLL_TRT ? pick_v<Q, ST, COLL_TRT, (MASK)>(V, P) : pick_v<Q, ST, COLL_SRT, (MASK)>(V, P);
 #define LBM_GENERIC(Q, ST) \
-	if (FO) return COLL == COLL_TRT ? launch_collide<Q, ST, COLL_TRT, -1, true> : launch_collide<Q, ST, COLL_SRT, -1, true>; \
+	if (FO) return V == 4 ? launch_fields_wide<Q, ST, 4> : V == 2 ? launch_fields_wide<Q, ST, 2> : launch_collide<Q, ST, COLL_SRT, -1, true>; /* the moments do not depend on the collision operator */ \
 	if (FEAT < 0) return COLL == COLL_TRT ? pick_v<Q, ST, COLL_TRT, -1>(V, P) : pick_v<Q, ST, COLL_SRT, -1>(V, P);
 
 } // namespace lbm

@@ -142,12 +142,14 @@ template <class raw2, int V, class rvec> __device__ __forceinline__ void set_pai
 // so nothing else touches them in between.  Waves without any active cell leave before loading anything.
 // P = 1: the V cells are collided one after the other; P = 2: two at a time in packed FP32 arithmetic (half the vector
 // arithmetic instructions, twice the live registers) - same bits either way.
-template <int Q, int ST, int COLL, int FEAT, int V, int P>
+// FO = true is update_fields (kernel.cpp:1812-1894) with the same loads: moments only, rho/u written as whole vectors, no DDF stores (P = 1).
+template <int Q, int ST, int COLL, int FEAT, int V, int P, bool FO = false>
 __global__ __launch_bounds__(256) void k_collide_wide(const Args a) {
 	using S = Store<ST>;
 	using raw = typename S::raw;
 	static_assert(V == 2 || V == 4, "vectors of 2 or 4 cells");
 	static_assert(P == 1 || P == 2, "cells collided together");
+	static_assert(!FO || P == 1, "update_fields handles its cells one after the other");
 	typedef raw rvec __attribute__((ext_vector_type(V)));
 	typedef uint8_t fvec __attribute__((ext_vector_type(V)));
 	typedef typename std::conditional<sizeof(raw) == 2, uint32_t, raw>::type lane_t; // what travels through a wave shuffle
@@ -256,16 +258,17 @@ __global__ __launch_bounds__(256) void k_collide_wide(const Args a) {
 				static_for<0, Q, 1>([&](auto I) { f[I] = S::decode(d[I][v]); });
 				if (feat(F_MOVING_BOUNDARIES) && bo == TYPE_MS) apply_moving_boundaries<Q>(f, a, xv, yq, zq);
 				float rhon, uxn, uyn, uzn;
-				collide<Q, COLL, false>(f, feat, &bo, a, row0, xv, rhon, uxn, uyn, uzn, &wf[v]);
-				if (feat(F_UPDATE_FIELDS)) { out[0][v] = rhon; out[1][v] = uxn; out[2][v] = uyn; out[3][v] = uzn; }
-				// streaming part 1 in registers: the slot that held f[i] receives f[i+1] and vice versa (kernel.cpp:1339-1345)
-				S::template prescale<Q>(f);
-				d[0][v] = S::encode_scaled(f[0]);
-				static_for<1, Q, 2>([&](auto I) {
-					constexpr int i = I;
-					d[i][v] = S::encode_scaled(f[i+1]);
-					d[i+1][v] = S::encode_scaled(f[i]);
-				});
+				collide<Q, COLL, FO>(f, feat, &bo, a, row0, xv, rhon, uxn, uyn, uzn, &wf[v]);
+				if (FO || feat(F_UPDATE_FIELDS)) { out[0][v] = rhon; out[1][v] = uxn; out[2][v] = uyn; out[3][v] = uzn; }
+				if constexpr (!FO) { // streaming part 1 in registers: the slot that held f[i] receives f[i+1] and vice versa (kernel.cpp:1339-1345)
+					S::template prescale<Q>(f);
+					d[0][v] = S::encode_scaled(f[0]);
+					static_for<1, Q, 2>([&](auto I) {
+						constexpr int i = I;
+						d[i][v] = S::encode_scaled(f[i+1]);
+						d[i+1][v] = S::encode_scaled(f[i]);
+					});
+				}
 			}
 		} else {
 			if (active[v] || active[v+1]) { // an inactive partner is computed along and its result dropped
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(256) void k_collide_wide(const Args a) {
 	// ---- rho/u output (kernel.cpp:1581-1591): always whole aligned vectors.  Cells that do not write (solid, halo,
 	// equilibrium boundary) get the value they already hold: partially written memory sectors next to obstacles cost
 	// far more than re-writing a few unchanged values (UPDATE_FIELDS, FP16S, 6 % solid cells: 47 400 -> 55 100 MLUPs/s; without solids 56 100)
-	if (P == 1 && feat(F_UPDATE_FIELDS) && inrow) {
+	if (P == 1 && (FO || feat(F_UPDATE_FIELDS)) && inrow) {
 		bool all = true;
 #pragma unroll
 		for (int v = 0; v < V; v++) all = all && wf[v];
@@ -341,6 +344,8 @@ __global__ __launch_bounds__(256) void k_collide_wide(const Args a) {
 #pragma unroll
 		for (int k = 0; k < 4; k++) st(dst[k], 4u*x, out[k]);
 	}
+
+	if constexpr (FO) return;
 
 	// ---- streaming part 1 (kernel.cpp:1339-1345): write every vector back to where it came from
 	lane_t carry[Q]; // for shifted streams: the element that belongs into the neighbouring lane's aligned vector
@@ -450,38 +455,108 @@ template <int Q, int ST> __device__ __forceinline__ void load_f(const Args& a, u
 	});
 }
 
-// FluidX3D-master/src/kernel.cpp:1364-1446 (without SURFACE/TEMPERATURE)
-template <int Q, int ST> __global__ __launch_bounds__(256) void k_initialize(const Args a) {
-	using S = Store<ST>; using raw = typename S::raw;
-	const Cell c = cell_of_thread(a);
-	if (!c.valid || is_halo(a, c)) return;
-	const uint64_t n = c.n;
-	uint64_t j[Q]; neighbors<Q>(a, c.x, c.y, c.z, j);
-	uint8_t fl = a.flags[n];
+// FluidX3D-master/src/kernel.cpp:1364-1446 (without SURFACE/TEMPERATURE).
+// What a cell does before it stores its equilibrium DDFs: returns false for a cell the kernel skips (halo column), else its
+// density and velocity (cleared for solid cells as the reference does).  The owner lane also writes the cleared velocity
+// and the TYPE_MS mark back; a lane that only needs a neighbour's values (see k_initialize) passes owner = false.
+template <int Q> __device__ __forceinline__ bool initial_state(const Args& a, const uint32_t x, const uint32_t y, const uint32_t z, const uint64_t row0, const bool owner,
+                                                              float& rho, float& ux, float& uy, float& uz) {
+	if (a.hx && (x == 0u || x >= a.Nx-1u)) return false; // kernel.cpp:850-853
+	const uint32_t x4 = 4u*x;
+	uint8_t fl = ld<uint8_t>(a.flags+row0, x);
+	rho = ld<float>(a.rho+row0, x4);
+	ux = ld<float>(a.u+row0, x4); uy = ld<float>(a.u+a.N+row0, x4); uz = ld<float>(a.u+2ull*a.N+row0, x4);
 	const uint8_t bo = fl&TYPE_BO;
 	const bool moving_ext = (a.features&F_MOVING_BOUNDARIES) != 0u;
 	if (bo == TYPE_S) {
 		bool only_solid = true;
-		static_for<1, Q, 1>([&](auto I) { only_solid = only_solid && (a.flags[j[I]]&TYPE_BO) == TYPE_S; });
-		if (only_solid || !moving_ext) { a.u[n] = 0.0f; a.u[a.N+n] = 0.0f; a.u[2ull*a.N+n] = 0.0f; }
-	} else if (moving_ext && bo != TYPE_E) {
+		if (moving_ext) { // otherwise the velocity of every solid cell is cleared and the neighbours do not matter
+			uint64_t j[Q]; neighbors<Q>(a, x, y, z, j);
+			static_for<1, Q, 1>([&](auto I) { only_solid = only_solid && (a.flags[j[I]]&TYPE_BO) == TYPE_S; });
+		}
+		if (only_solid || !moving_ext) {
+			ux = uy = uz = 0.0f;
+			if (owner) { st(a.u+row0, x4, ux); st(a.u+a.N+row0, x4, uy); st(a.u+2ull*a.N+row0, x4, uz); }
+		}
+	} else if (owner && moving_ext && bo != TYPE_E) {
+		uint64_t j[Q]; neighbors<Q>(a, x, y, z, j);
 		bool moving = false;
 		static_for<1, Q, 1>([&](auto I) {
 			const uint64_t ji = j[I];
 			moving = moving || ((a.flags[ji]&TYPE_BO) == TYPE_S && (a.u[ji] != 0.0f || a.u[a.N+ji] != 0.0f || a.u[2ull*a.N+ji] != 0.0f));
 		});
 		fl = moving ? (uint8_t)(fl|TYPE_MS) : (uint8_t)(fl&~TYPE_MS);
-		a.flags[n] = fl;
+		st(a.flags+row0, x, fl);
 	}
-	float feq[Q];
-	f_eq<Q>(a.rho[n], a.u[n], a.u[a.N+n], a.u[2ull*a.N+n], feq);
-	raw* fi = static_cast<raw*>(a.fi); // store_f with t=1 (kernel.cpp:1445)
-	fi[n] = S::encode(feq[0]);
+	return true;
+}
+// One workgroup per lattice row chunk like k_collide (row bases wave-uniform).  store_f with t = 1 (kernel.cpp:1445) puts
+// f_eq[i+1] into stream i at the cell itself and f_eq[i] into stream i+1 at the cell's +c_i neighbour, i.e. one column to
+// the right or left when c_i has an x component.  A kernel that only stores must not leave memory sectors half written
+// (a wave's 64 stores shifted by one element cost 1.7x the time of aligned ones on MI355X), so every lane writes column x
+// of every stream: the value for a shifted stream comes from the neighbouring lane through a wave shuffle, and the lanes
+// at the two ends of a wave work out the neighbouring cell's equilibrium themselves.  Same bits in the same places.
+template <int Q, int ST> __global__ __launch_bounds__(256) void k_initialize(const Args a) {
+	using S = Store<ST>; using raw = typename S::raw;
+	const uint32_t chunk = blockIdx.x%a.xchunks, y = blockIdx.x/a.xchunks, z = blockIdx.y;
+	if ((a.hy && (y == 0u || y >= a.Ny-1u)) || (a.hz && (z == 0u || z >= a.Nz-1u))) return; // kernel.cpp:850-853
+	const uint32_t x = chunk*blockDim.x+threadIdx.x, lane = threadIdx.x&63u;
+	if (x >= a.Nx) return; // no lane in the row ever takes a value from these
+	const uint32_t yq[3] = {y, y+1u == a.Ny ? 0u : y+1u, y == 0u ? a.Ny-1u : y-1u}; // index 0: same, 1: +1, 2: -1
+	const uint32_t zq[3] = {z, z+1u == a.Nz ? 0u : z+1u, z == 0u ? a.Nz-1u : z-1u};
+	const uint64_t row0 = ((uint64_t)z*a.Ny+y)*a.Nx;
+	raw* const fi = static_cast<raw*>(a.fi);
+	raw* pa[Q];
+	pa[0] = fi+row0;
 	static_for<1, Q, 2>([&](auto I) {
-		constexpr int i = I;
-		fi[(uint64_t)(i+1)*a.S+j[i]] = S::encode(feq[i]);
-		fi[(uint64_t)i*a.S+n] = S::encode(feq[i+1]);
+		constexpr int i = I, cy = dir<Q>(i,1), cz = dir<Q>(i,2);
+		pa[i] = fi+(uint64_t)i*a.S+row0;
+		pa[i+1] = fi+(uint64_t)(i+1)*a.S+((uint64_t)zq[cz == 0 ? 0 : cz > 0 ? 1 : 2]*a.Ny+yq[cy == 0 ? 0 : cy > 0 ? 1 : 2])*a.Nx;
 	});
+	typedef typename std::conditional<sizeof(raw) == 2, uint32_t, raw>::type lane_t; // what travels through a wave shuffle
+	float rho, ux, uy, uz;
+	const bool valid = initial_state<Q>(a, x, y, z, row0, true, rho, ux, uy, uz);
+	raw e[Q]; // the cell's encoded equilibrium
+	{
+		float feq[Q];
+		f_eq<Q>(valid ? rho : 1.0f, valid ? ux : 0.0f, valid ? uy : 0.0f, valid ? uz : 0.0f, feq);
+		static_for<0, Q, 1>([&](auto I) { e[I] = S::encode(feq[I]); });
+	}
+	// the cell to the left gives the values of the streams with c_x > 0, the cell to the right those with c_x < 0 (periodic)
+	const bool seam_lo = lane == 0u, seam_hi = lane == 63u || x+1u == a.Nx;
+	bool from_lo = __shfl_up((int)valid, 1) != 0, from_hi = __shfl_down((int)valid, 1) != 0;
+	raw shifted[Q];
+	static_for<1, Q, 2>([&](auto I) {
+		constexpr int i = I, cx = dir<Q>(i,0);
+		shifted[i+1] = e[i];
+		if constexpr (cx > 0) shifted[i+1] = (raw)__shfl_up((lane_t)e[i], 1);
+		if constexpr (cx < 0) shifted[i+1] = (raw)__shfl_down((lane_t)e[i], 1);
+	});
+	auto neighbour_cell = [&](const uint32_t xn, const bool plus, bool& from) { // the lane works out cell xn's equilibrium for the streams it needs
+		float r, vx, vy, vz;
+		from = initial_state<Q>(a, xn, y, z, row0, false, r, vx, vy, vz);
+		if (from) {
+			float feq[Q];
+			f_eq<Q>(r, vx, vy, vz, feq);
+			static_for<1, Q, 2>([&](auto I) {
+				constexpr int i = I, cx = dir<Q>(i,0);
+				if constexpr (cx != 0) if ((cx > 0) == plus) shifted[i+1] = S::encode(feq[i]);
+			});
+		}
+	};
+	if (seam_lo) neighbour_cell(x == 0u ? a.Nx-1u : x-1u, true, from_lo);
+	if (seam_hi) neighbour_cell(x+1u == a.Nx ? 0u : x+1u, false, from_hi);
+	const uint32_t xb = fresh(x*(uint32_t)sizeof(raw));
+	if (valid) {
+		st(pa[0], xb, e[0]);
+		static_for<1, Q, 2>([&](auto I) {
+			constexpr int i = I;
+			st(pa[i], xb, e[i+1]);
+			if constexpr (dir<Q>(i,0) == 0) st(pa[i+1], xb, shifted[i+1]);
+		});
+	}
+	if (from_lo) static_for<1, Q, 2>([&](auto I) { constexpr int i = I; if constexpr (dir<Q>(i,0) > 0) st(pa[i+1], xb, shifted[i+1]); });
+	if (from_hi) static_for<1, Q, 2>([&](auto I) { constexpr int i = I; if constexpr (dir<Q>(i,0) < 0) st(pa[i+1], xb, shifted[i+1]); });
 }
 
 // FluidX3D-master/src/kernel.cpp:1897-1910
