@@ -2,6 +2,7 @@
 """Profiles one configuration of tools/config_bench.py with rocprofv3 on the GPU box and writes the tracked summary.
 
   python3 tools/profile_config.py <tag> <config-name> [more config_bench arguments]
+  python3 tools/profile_config.py <tag> <update_fields|initialize>_<fp32|fp16s|fp16c> --bench=tools/aux_bench.py --kernel=<name part>
 
 Passes (each its own process; counters never share a run with traces):
   1. plain run: the library's geometry search picks (cells per lane, cells together, residency cap, workgroup size)
@@ -40,11 +41,13 @@ def run(cmd, log, limit):
 
 
 def main():
-    tag, name, extra = sys.argv[1], sys.argv[2], sys.argv[3:]
+    tag, name, extra = sys.argv[1], sys.argv[2], [a for a in sys.argv[3:] if not a.startswith(("--bench=", "--kernel="))]
+    script = next((a.split("=", 1)[1] for a in sys.argv[3:] if a.startswith("--bench=")), "tools/config_bench.py")
+    kernel_part = next((a.split("=", 1)[1] for a in sys.argv[3:] if a.startswith("--kernel=")), "k_collide")
     out = os.path.join(ROOT, "gpurun_out", "prof_%s_%s" % (tag, name))
     shutil.rmtree(out, ignore_errors=True)
     os.makedirs(out)
-    bench = ["python3", "tools/config_bench.py", name] + extra
+    bench = ["python3", script, name] + extra
     text = run(bench, os.path.join(out, "tune.log"), 600)
     m = re.search(r"(\d+) MLUPs/s +(\d+) B/cell.*\[tuned=(\d) V=(\d+) P=(\d+) blocks/CU<=(-?\d+) block=(\d+)\]", text)
     if not m:
@@ -65,7 +68,7 @@ def main():
     newest = lambda pattern: max(glob.glob(pattern), key=os.path.getmtime)
     stats_csv = newest(os.path.join(out, "stats", "*", "*kernel_stats.csv"))
     shutil.copy(stats_csv, prefix + "_kernel_stats.csv")
-    kernels = [r for r in csv.DictReader(open(stats_csv)) if "k_collide" in r["Name"]]
+    kernels = [r for r in csv.DictReader(open(stats_csv)) if kernel_part in r["Name"]]
     step = max(kernels, key=lambda r: int(r["Calls"]))
     avg_ns = float(step["AverageNs"])
 

@@ -54,7 +54,9 @@ if main:
     if key:
         tpath = os.path.join(dst, "traffic.json")
         t = json.load(open(tpath)) if os.path.exists(tpath) else {}
-        t[key] = round(read_bytes + write_bytes)
+        t[key] = {"bytes_per_launch": round(read_bytes + write_bytes), "kernel": main[0],
+                  "source": "profiles/%s_pmc_summary.csv (rocprofv3 --pmc passes of bench.py; 2 x FETCH_SIZE + WRITE_SIZE; library at commit %s)" % (
+                      tag, os.popen("git -C %s rev-parse --short HEAD" % ROOT).read().strip() or "unknown")}
         json.dump(t, open(tpath, "w"), indent=1, sort_keys=True)
 json.dump(out, open(os.path.join(dst, "%s_summary.json" % tag), "w"), indent=1, sort_keys=True)
 print(json.dumps(out, indent=1))
