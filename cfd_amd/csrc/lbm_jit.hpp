@@ -4,9 +4,9 @@
 // runs code specialised for exactly its feature set (FluidX3D-master/src/lbm.cpp:424-665, opencl.hpp:285-300).  The
 // counterpart here: the kernel templates of lbm_kernels.hpp are embedded in the library as text, and the first launch of a
 // feature set that has no precompiled instance compiles <Q, storage, collision, features> for the five launch geometries
-// with hipRTC (2-4 s, once per process and device).  Same compiler and flags as the precompiled instances, hence the same
-// bits.  hipRTC is looked up at run time; without it, or if the compilation fails, the run-time-feature instances are used.
-// LBMHIP_JIT=0 switches this off.
+// with hipRTC (1.5-4 s by velocity set, once per process and device).  Same compiler and flags as the precompiled instances,
+// hence the same bits.  hipRTC is looked up at run time; without it, or if the compilation fails, the run-time-feature
+// instances are used (same results, 10-50 % slower) and one line on stderr says so.  LBMHIP_JIT=0 switches this off.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
@@ -60,16 +60,24 @@ inline const Rtc& rtc() {
 	return api;
 }
 
-// the compiled instance for (device, Q, ST, COLL, FEAT), or nullptr when it cannot be had (reason printed once to stderr
-// when LBMHIP_JIT_VERBOSE is set).  small: D2Q9 / D3Q15, which only run one cell per lane.
+// the compiled instance for (device, Q, ST, COLL, FEAT), or nullptr when it cannot be had (said once per feature set on
+// stderr; the compiler's log with LBMHIP_JIT_VERBOSE).  small: D2Q9 / D3Q15, which only run one cell per lane.
+// Compilations of different feature sets or devices run side by side: the table is locked only to look an entry up or to
+// create it, and each entry has its own lock for the seconds its compilation takes.
+struct Entry { std::mutex busy; bool done = false; Instance* inst = nullptr; };
 inline const Instance* instance(int device, int Q, int ST, int COLL, int FEAT, bool small) {
-	static std::mutex mutex;
-	static std::map<std::tuple<int, int, int, int, int>, Instance*> cache; // failed attempts are cached as nullptr
+	static std::mutex table_lock;
+	static std::map<std::tuple<int, int, int, int, int>, Entry*> cache; // failed attempts stay cached with inst == nullptr
 	{ const char* e = getenv("LBMHIP_JIT"); if (e && e[0] == '0') return nullptr; }
-	std::lock_guard<std::mutex> lock(mutex);
-	const auto key = std::make_tuple(device, Q, ST, COLL, FEAT);
-	const auto found = cache.find(key);
-	if (found != cache.end()) return found->second;
+	Entry* entry = nullptr;
+	{
+		std::lock_guard<std::mutex> lock(table_lock);
+		Entry*& slot = cache[std::make_tuple(device, Q, ST, COLL, FEAT)];
+		if (!slot) slot = new Entry();
+		entry = slot;
+	}
+	std::lock_guard<std::mutex> lock(entry->busy);
+	if (entry->done) return entry->inst;
 	Instance* result = nullptr;
 	const bool verbose = getenv("LBMHIP_JIT_VERBOSE") != nullptr;
 	const Rtc& api = rtc();
@@ -112,11 +120,20 @@ inline const Instance* instance(int device, int Q, int ST, int COLL, int FEAT, b
 			good = api.lowered_name(prog, name[k], &lowered) == 0 && lowered && hipModuleGetFunction(&inst->fn[k], module, lowered) == hipSuccess;
 		}
 		api.destroy(&prog);
-		if (!good) { (void)hipGetLastError(); delete inst; if (verbose) std::fprintf(stderr, "lbmhip jit: loading the compiled module failed\n"); break; }
+		if (!good) {
+			(void)hipGetLastError();
+			if (module) (void)hipModuleUnload(module);
+			delete inst;
+			if (verbose) std::fprintf(stderr, "lbmhip jit: loading the compiled module failed\n");
+			break;
+		}
 		if (verbose) std::fprintf(stderr, "lbmhip jit: compiled D?Q%d storage %d collision %d features 0x%x for device %d\n", Q, ST, COLL, (unsigned)FEAT, device);
 		result = inst; // the module stays loaded for the life of the process
 	} while (false);
-	cache[key] = result;
+	if (!result) std::fprintf(stderr, "lbmhip: no kernel could be compiled for D?Q%d storage %d collision %d features 0x%x on device %d; using the kernels that test the features at run time (same results, slower; LBMHIP_JIT_VERBOSE=1 shows why)\n",
+	                          Q, ST, COLL, (unsigned)FEAT, device);
+	entry->inst = result;
+	entry->done = true;
 	return result;
 }
 

@@ -40,7 +40,7 @@ struct lbmhip_domain {
 	hipEvent_t ev_fork, ev_join;
 	void* halo_own[4];
 	void* halo[4];
-	uint64_t halo_capacity;
+	uint64_t halo_capacity, halo_own_capacity; // of the buffers in use / of the library's own buffers
 	hipEvent_t ev_start, ev_stop, ev_packed, ev_copied;
 	int cells_per_thread, cells_together, block, blocks_per_cu;
 	// launch-geometry search over the first full-lattice stream_collide launches (results do not depend on the geometry)
@@ -260,7 +260,7 @@ int lbmhip_domain_create(const lbmhip_config* c, lbmhip_domain** out) {
 		if (c->Dx > 1u) amax = std::max<uint64_t>(amax, (uint64_t)c->Ny*c->Nz);
 		if (c->Dy > 1u) amax = std::max<uint64_t>(amax, (uint64_t)c->Nz*c->Nx);
 		if (c->Dz > 1u) amax = std::max<uint64_t>(amax, (uint64_t)c->Nx*c->Ny);
-		d->halo_capacity = amax*std::max<uint32_t>(q_transfers(c->velocity_set)*d->fpxx_bytes, 17u);
+		d->halo_capacity = d->halo_own_capacity = amax*std::max<uint32_t>(q_transfers(c->velocity_set)*d->fpxx_bytes, 17u);
 		for (int k = 0; k < 4; k++) {
 			e = hipMalloc(&d->halo_own[k], d->halo_capacity);
 			if (e != hipSuccess) { cleanup(); return fail("allocating halo staging buffers failed: %s", hipGetErrorString(e)); }
@@ -695,6 +695,7 @@ int lbmhip_halo_set_buffers(lbmhip_domain* d, void* send_p, void* send_m, void* 
 	NEED(d, "null domain");
 	if (!send_p && !send_m && !recv_p && !recv_m) { // back to the library's own buffers
 		for (int k = 0; k < 4; k++) d->halo[k] = d->halo_own[k];
+		d->halo_capacity = d->halo_own_capacity;
 		return 0;
 	}
 	NEED(send_p && send_m && recv_p && recv_m, "all four staging buffers must be given");
@@ -712,8 +713,11 @@ int lbmhip_halo_set_buffers(lbmhip_domain* d, void* send_p, void* send_m, void* 
 // Direct device-to-device copies over xGMI need peer access switched on once per ordered device pair; without it
 // hipMemcpyPeerAsync still works but stages through host memory.  Failure to enable it is therefore not an error.
 static void enable_peer_access(int device, int peer) {
+	static std::mutex lock; // handles are owned by one thread each, but this table is shared by all of them
 	static bool tried[64][64];
-	if (device == peer || device < 0 || peer < 0 || device >= 64 || peer >= 64 || tried[device][peer]) return;
+	if (device == peer || device < 0 || peer < 0 || device >= 64 || peer >= 64) return;
+	std::lock_guard<std::mutex> hold(lock);
+	if (tried[device][peer]) return;
 	tried[device][peer] = true;
 	DeviceGuard g(device);
 	int can = 0;
@@ -725,10 +729,17 @@ static void enable_peer_access(int device, int peer) {
 
 int lbmhip_halo_exchange_local(lbmhip_domain** doms, uint32_t count, int what, int axis) {
 	NEED(doms && count > 0u, "null argument");
+	for (uint32_t k = 0; k < count; k++) NEED(doms[k], "domain %u of %u is null", k, count);
 	const lbmhip_config& c0 = doms[0]->cfg;
 	NEED(count == c0.Dx*c0.Dy*c0.Dz, "expected %u domains, got %u", c0.Dx*c0.Dy*c0.Dz, count);
 	for (uint32_t k = 0; k < count; k++) if (halo_check(doms[k], what, axis)) return 1;
 	const uint64_t bytes = face_area(doms[0], axis)*halo_bytes_per_cell(doms[0], what);
+	for (uint32_t k = 0; k < count; k++) { // one message size for all: the domains must be blocks of the same decomposition
+		const lbmhip_config& c = doms[k]->cfg;
+		NEED(c.Nx == c0.Nx && c.Ny == c0.Ny && c.Nz == c0.Nz && c.Dx == c0.Dx && c.Dy == c0.Dy && c.Dz == c0.Dz && c.velocity_set == c0.velocity_set && c.storage == c0.storage,
+		     "domain %u differs from domain 0 in size, decomposition, velocity set or DDF storage", k);
+		NEED(bytes <= doms[k]->halo_capacity, "staging buffers of domain %u too small (%llu bytes, %llu needed)", k, (unsigned long long)doms[k]->halo_capacity, (unsigned long long)bytes);
+	}
 	for (uint32_t k = 0; k < count; k++) { // every domain's pack is complete once its own stream reaches this event
 		DeviceGuard g(doms[k]->cfg.device);
 		HIP_TRY(hipEventRecord(doms[k]->ev_packed, doms[k]->stream));

@@ -1,5 +1,8 @@
-// units.hpp - SI <-> lattice unit conversion with the method names of the reference's Units class
-// (FluidX3D-master/src/units.hpp:5-161), so that setups written for it compile unchanged.
+// units.hpp - SI <-> lattice unit conversion.  The method names, argument orders and meanings MIRROR the reference's Units
+// class (FluidX3D-master/src/units.hpp:5-161) on purpose: setups written for the reference call them and must compile
+// unchanged.  Only what the reference's lattice-Boltzmann setups without free surface, temperature or particles call is
+// provided (base units, SI <-> lattice conversions, Reynolds number, viscosity/velocity/force relations, Poiseuille and
+// Stokes flow); the other dimensionless numbers and *_from_* helpers of the reference's class are left out.
 // Outputs are converted by their dimension: one lattice unit of a quantity with dimension m^L kg^M s^T K^H is
 // dim(L, M, T, H) SI units and "si_q(v)" multiplies by it.
 #pragma once
@@ -72,54 +75,16 @@ public:
 	float si_alpha(const float alpha) const { return alpha*dim(2, 0, -1); }
 	float si_beta(const float beta) const { return beta*dim(0, 0, 0, -1); }
 
-	// ---- dimensionless numbers (the same in both unit systems)
-	float Re(const float si_Re) const { return si_Re; }
-	float Re(const float x, const float u, const float nu) const { return x*u/nu; }                                  // Reynolds
-	float Re(const float x, const float u, const float mu, const float rho) const { return x*u*rho/mu; }
-	float We(const float x, const float u, const float rho, const float sigma) const { return x*sq(u)*rho/sigma; }   // Weber
-	float Fr(const float x, const float u, const float g) const { return u/std::sqrt(x*g); }                         // Froude
-	float Ca(const float u, const float mu, const float sigma) const { return u*mu/sigma; }                          // capillary
-	float Ca(const float u, const float rho, const float nu, const float sigma) const { return u*rho*nu/sigma; }
-	float Bo(const float x, const float rho, const float g, const float sigma) const { return sq(x)*rho*g/sigma; }   // Bond
-	float Mo(const float rho, const float delta_rho, const float g, const float sigma, const float mu) const { return g*delta_rho*sq(sq(mu))/(cb(sigma)*sq(rho)); } // Morton
-	float Ga(const float x, const float nu, const float g) const { return cb(x)*g/sq(nu); }                          // Galilei
-	float Ga(const float x, const float rho, const float nu, const float f) const { return cb(x)*f/(sq(nu)*rho); }
-	float Ma(const float u) const { return u/0.57735027f; }                                                          // Mach, lattice speed of sound 1/sqrt(3)
+	// ---- Reynolds number (the same in both unit systems)
 	float si_Re(const float Re) const { return Re; }
 	float si_Re(const float si_x, const float si_u, const float si_nu) const { return si_x*si_u/si_nu; }
 	float si_Re(const float si_x, const float si_u, const float si_mu, const float si_rho) const { return si_x*si_u*si_rho/si_mu; }
-	float si_We(const float si_x, const float si_u, const float si_rho, const float si_sigma) const { return si_x*sq(si_u)*si_rho/si_sigma; }
-	float si_Fr(const float si_x, const float si_u, const float si_g) const { return si_u/std::sqrt(si_x*si_g); }
-	float si_Ca(const float si_u, const float si_mu, const float si_sigma) const { return si_u*si_mu/si_sigma; }
-	float si_Ca(const float si_u, const float si_rho, const float si_nu, const float si_sigma) const { return si_u*si_rho*si_nu/si_sigma; }
-	float si_Bo(const float si_x, const float si_rho, const float si_g, const float si_sigma) const { return sq(si_x)*si_rho*si_g/si_sigma; }
-	float si_Mo(const float si_rho, const float si_delta_rho, const float si_g, const float si_sigma, const float si_mu) const { return si_g*si_delta_rho*sq(sq(si_mu))/(cb(si_sigma)*sq(si_rho)); }
-	float si_Ga(const float si_x, const float si_nu, const float si_g) const { return cb(si_x)*si_g/sq(si_nu); }
-	float si_Ga(const float si_x, const float si_rho, const float si_nu, const float si_f) const { return cb(si_x)*si_f/(sq(si_nu)*si_rho); }
 
 	// ---- relations in lattice units: equation of state p = (rho-1)/3, viscosity from relaxation time, parameters from numbers
-	float p_from_rho(const float rho) const { return (rho-1.0f)/3.0f; }
-	float rho_from_p(const float p) const { return 1.0f+3.0f*p; }
-	float rho_laplace(const float sigma, const float R) const { return 6.0f*sigma/R; }                 // 3 x Laplace pressure 2 sigma/R of a sphere
-	float rho_hydrostatic(const float f, const float z, const float h) const { return 3.0f*f*(h-z)+1.0f; } // 3 x (f (h-z) + 1/3)
-	float nu_from_mu(const float mu, const float rho) const { return mu/rho; }
 	float nu_from_tau(const float tau) const { return (tau-0.5f)/3.0f; }
 	float nu_from_Re(const float Re, const float x, const float u) const { return x*u/Re; }
-	float f_from_F(const float F, const float V) const { return F/V; }
-	float f_from_g(const float g, const float rho) const { return rho*g; }
-	float g_from_f(const float f, const float rho) const { return f/rho; }
 	float u_from_Re(const float Re, const float x, const float nu) const { return Re*nu/x; }
-	float u_from_Re(const float Re, const float x, const float mu, const float rho) const { return Re*mu/(x*rho); }
-	float u_from_Ma(const float Ma) const { return 0.57735027f*Ma; }
-	float u_from_We(const float We, const float x, const float sigma, const float rho) const { return std::sqrt(We*sigma/(x*rho)); }
-	float u_from_Fr(const float Fr, const float x, const float g) const { return Fr*std::sqrt(x*g); }
-	float u_from_Ca(const float Ca, const float sigma, const float nu, const float rho) const { return Ca*sigma/(rho*nu); }
-	float u_from_Ca(const float Ca, const float sigma, const float mu) const { return Ca*sigma/mu; }
-	// Poiseuille flow: centre velocity u = f R^2 / (2 rho nu) between plates, f R^2 / (4 rho nu) in a pipe; from the flow rate: 3Q/(4R), 2Q/(pi R^2)
-	float u_from_f_Poiseuille_2D(const float f, const float rho, const float nu, const float R) const { return f*sq(R)/(2.0f*rho*nu); }
-	float u_from_f_Poiseuille_3D(const float f, const float rho, const float nu, const float R) const { return f*sq(R)/(4.0f*rho*nu); }
-	float u_from_f_Poiseuille_2D(const float Q, const float R) const { return 0.75f*Q/R; }
-	float u_from_f_Poiseuille_3D(const float Q, const float R) const { return 2.0f/pif*Q/sq(R); }
+	// Poiseuille flow: centre velocity u = f R^2 / (2 rho nu) between plates, f R^2 / (4 rho nu) in a pipe
 	float f_from_u_Poiseuille_2D(const float u, const float rho, const float nu, const float R) const { return 2.0f*u*rho*nu/sq(R); }
 	float f_from_u_Poiseuille_3D(const float u, const float rho, const float nu, const float R) const { return 4.0f*u*rho*nu/sq(R); }
 	// rectangular duct of width w and height h: centre velocity u = (4 h^2 f / (pi^3 rho nu)) * sum over odd n of (1 - 1/cosh(n pi w / 2h)) sin(n pi/2) / n^3
@@ -130,9 +95,8 @@ public:
 		const double pi3 = 3.14159265358979323846*3.14159265358979323846*3.14159265358979323846;
 		return (float)(pi3*(double)rho*(double)nu*(double)u/(4.0*(double)h*(double)h)/series);
 	}
-	// Stokes flow past a sphere of radius R: drag 6 pi rho nu R u, as a force or per volume V
+	// Stokes flow past a sphere of radius R: drag 6 pi rho nu R u
 	float F_Stokes(const float rho, const float u, const float nu, const float R) const { return 6.0f*pif*rho*nu*R*u; }
-	float f_Stokes(const float rho, const float u, const float nu, const float R, const float V) const { return 6.0f*pif*rho*nu*R*u/V; }
 	// creeping flow of far-field velocity u0 past a fixed sphere of radius R at the origin (FluidX3D-master/src/units.hpp:125-132):
 	// u = u0 - (3R/4)(u0/r + x (u0.x)/r^3) - (R^3/4)(u0/r^3 - 3 x (u0.x)/r^5), p = -(3/2) rho nu R (u0.x)/r^3, rho = rho0 + 3p
 	float3 u_Stokes(const float3& x, const float3& u0, const float R) const {
@@ -147,17 +111,6 @@ public:
 	}
 
 	// ---- the same relations for SI inputs
-	float si_nu_from_si_mu(const float si_mu, const float si_rho) const { return si_mu/si_rho; }
-	float si_mu_from_si_nu(const float si_nu, const float si_rho) const { return si_nu*si_rho; }
-	float si_nu_from_si_Re(const float si_Re, const float si_x, const float si_u) const { return si_x*si_u/si_Re; }
-	float si_u_from_si_Re(const float si_Re, const float si_x, const float si_nu) const { return si_Re*si_nu/si_x; }
-	float si_u_from_si_Re(const float si_Re, const float si_x, const float si_mu, const float si_rho) const { return si_Re*si_mu/(si_x*si_rho); }
-	float si_u_from_si_We(const float si_We, const float si_x, const float si_sigma, const float si_rho) const { return std::sqrt(si_We*si_sigma/(si_x*si_rho)); }
-	float si_u_from_si_Fr(const float si_Fr, const float si_x, const float si_g) const { return si_Fr*std::sqrt(si_x*si_g); }
-	float si_u_from_si_h(const float si_h, const float si_g) const { return std::sqrt(2.0f*si_h*si_g); }          // free fall from height h
 	float si_f_from_si_g(const float si_g, const float si_rho) const { return si_rho*si_g; }
-	float si_g_from_si_f(const float si_f, const float si_rho) const { return si_f/si_rho; }
-	float si_u_Poiseuille_2D(const float si_Q, const float si_R) const { return 0.75f*si_Q/si_R; }
-	float si_u_Poiseuille_3D(const float si_Q, const float si_R) const { return 2.0f/pif*si_Q/sq(si_R); }
 };
 extern Units units; // defined in lbm.cpp (FluidX3D-master/src/lbm.cpp:3)

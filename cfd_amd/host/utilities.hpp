@@ -117,20 +117,66 @@ inline string to_string(const int x) { return std::to_string(x); }
 inline string to_string(const ulong x) { return std::to_string((unsigned long long)x); }
 inline string to_string(const slong x) { return std::to_string((long long)x); }
 // d.dddd[E<exponent>] with the mantissa in [1,10) and the exponent left out when it is 0: the text format of the reference's
-// to_string(float) / to_string(double) (FluidX3D-master/src/utilities.hpp:2745-2765), which its VTK headers and status files carry
-inline string scientific(const double x, const int decimals) {
-	if (std::isnan(x)) return "NaN";
-	if (std::isinf(x)) return x < 0.0 ? "-Inf" : "Inf";
-	char b[64]; std::snprintf(b, sizeof(b), "%.*E", decimals, x);
-	char* e = std::strchr(b, 'E');
-	const int exponent = std::atoi(e+1);
-	*e = 0;
-	return string(b)+(exponent != 0 ? "E"+std::to_string(exponent) : "");
+// to_string(float) / to_string(double): "d.dddddddd[E<exponent>]" with 8 or 16 decimals.  The reference extracts the digits
+// itself, in the arithmetic of the number's own type (FluidX3D-master/src/utilities.hpp:2599-2668, 2745-2765): scale into
+// [1, 10) by powers 10^(2^k), cut the leading digit, multiply the rest by 10^decimals, round half up.  Those float products
+// are rounded, so the last digits can differ from a correctly rounded conversion (24.87301 prints as 2.48730112E1, printf
+// gives 2.48730106E1); VTK headers and status files carry these strings, so the same steps are taken here.
+template <typename F> struct decimal_steps;
+template <> struct decimal_steps<float> {
+	static constexpr int count = 6, decimals = 8;
+	static constexpr float up[6] = {1E32f, 1E16f, 1E8f, 1E4f, 1E2f, 1E1f}, down[6] = {1E-32f, 1E-16f, 1E-8f, 1E-4f, 1E-2f, 1E-1f};
+	static constexpr float below[6] = {1E-31f, 1E-15f, 1E-7f, 1E-3f, 1E-1f, 1E0f}; // x < 10^-(e-1) is lifted by 10^e
+	static constexpr int exponent[6] = {32, 16, 8, 4, 2, 1};
+	static constexpr float scale = 1E8f;
+	typedef uint digits_t;
+};
+template <> struct decimal_steps<double> {
+	static constexpr int count = 9, decimals = 16;
+	static constexpr double up[9] = {1E256, 1E128, 1E64, 1E32, 1E16, 1E8, 1E4, 1E2, 1E1}, down[9] = {1E-256, 1E-128, 1E-64, 1E-32, 1E-16, 1E-8, 1E-4, 1E-2, 1E-1};
+	static constexpr double below[9] = {1E-255, 1E-127, 1E-63, 1E-31, 1E-15, 1E-7, 1E-3, 1E-1, 1E0};
+	static constexpr int exponent[9] = {256, 128, 64, 32, 16, 8, 4, 2, 1};
+	static constexpr double scale = 1E16;
+	typedef ulong digits_t;
+};
+inline string zero_padded(ulong v, const int digits) { string r((size_t)digits, '0'); for (int k = digits-1; k >= 0; k--) { r[(size_t)k] = (char)('0'+v%10ull); v /= 10ull; } return r; }
+template <typename F> inline string scientific(F x) {
+	typedef decimal_steps<F> S;
+	string sign;
+	if (x < (F)0) { sign = "-"; x = -x; }
+	if (std::isnan(x)) return sign+"NaN";
+	if (std::isinf(x)) return sign+"Inf";
+	int exponent = 0;
+	if (x >= (F)10) for (int k = 0; k < S::count; k++) if (x >= S::up[k]) { x *= S::down[k]; exponent += S::exponent[k]; }
+	if (x > (F)0 && x <= (F)1) for (int k = 0; k < S::count; k++) if (x < S::below[k]) { x *= S::up[k]; exponent -= S::exponent[k]; }
+	uint leading = (uint)x;
+	const F rest = (x-(F)leading)*S::scale;
+	typename S::digits_t decimal = (typename S::digits_t)rest;
+	if (rest-(F)decimal >= (F)0.5) { // round half up; a carry may run through all digits
+		decimal++;
+		if ((F)decimal >= S::scale) { decimal = 0; if (++leading >= 10u) { leading = 1u; exponent++; } }
+	}
+	return sign+std::to_string(leading)+"."+zero_padded((ulong)decimal, S::decimals)+(exponent != 0 ? "E"+std::to_string(exponent) : "");
 }
-inline string to_string(const float x) { return scientific((double)x, 8); }
-inline string to_string(const double x) { return scientific(x, 16); }
-inline string to_string(const float x, const uint decimals) { char b[64]; std::snprintf(b, sizeof(b), "%.*f", (int)decimals, (double)x); return string(b); }
-inline string to_string(const double x, const uint decimals) { char b[64]; std::snprintf(b, sizeof(b), "%.*f", (int)decimals, x); return string(b); }
+inline string to_string(const float x) { return scientific<float>(x); }
+inline string to_string(const double x) { return scientific<double>(x); }
+// fixed notation with a given number of decimals (utilities.hpp:2766-2787): half of the last place is added, then the
+// digits are cut, all in the number's own type
+template <typename F> inline string fixed_decimals(F x, const uint decimals) {
+	typedef decimal_steps<F> S;
+	string sign;
+	if (x < (F)0) { sign = "-"; x = -x; }
+	if (std::isnan(x)) return sign+"NaN";
+	if (std::isinf(x) || x > (F)max_ulong) return sign+"Inf";
+	const int kept = (int)std::min(decimals, (uint)S::decimals);
+	const F power = (F)std::pow((F)10, (F)kept);
+	x += (F)0.5/power;
+	const ulong whole = (ulong)x;
+	const typename S::digits_t decimal = (typename S::digits_t)((x-(F)whole)*power);
+	return sign+std::to_string(whole)+(decimals == 0u ? "" : "."+zero_padded((ulong)decimal, kept));
+}
+inline string to_string(const float x, const uint decimals) { return fixed_decimals<float>(x, decimals); }
+inline string to_string(const double x, const uint decimals) { return fixed_decimals<double>(x, decimals); }
 inline uint length(const string& s) { return (uint)s.length(); }
 inline string substring(const string& s, const uint start, const uint n) { return s.substr(start, n); }
 inline void print(const string& s = "") { std::cout << s; }

@@ -72,6 +72,33 @@ def device_count():
     return n.value
 
 
+def float_string(v):
+    """A float as the reference prints it, d.dddddddd[E<exponent>] (utilities.hpp:2599-2630, 2745-2754): the digits are taken
+    in float32 arithmetic (scale into [1, 10) by 10^32 ... 10^1, cut the first digit, rest * 10^8, round half up), so the
+    last digits can differ from a correctly rounded conversion; file headers carry these strings."""
+    f = np.float32
+    x, sign, e = f(abs(v)), "-" if v < 0 else "", 0
+    with np.errstate(over="ignore", under="ignore"):
+        if x >= f(10.0):
+            for p in (32, 16, 8, 4, 2, 1):
+                if x >= f(float("1e%d" % p)):
+                    x, e = f(x * f(float("1e-%d" % p))), e + p
+        if f(0.0) < x <= f(1.0):
+            for p in (32, 16, 8, 4, 2, 1):
+                if x < f(float("1e-%d" % (p - 1))):
+                    x, e = f(x * f(float("1e%d" % p))), e - p
+        lead = int(x)
+        rest = f(f(x - f(lead)) * f(1e8))
+        dec = int(rest)
+        if f(rest - f(dec)) >= f(0.5):
+            dec += 1
+            if dec >= 100000000:
+                dec, lead = 0, lead + 1
+                if lead >= 10:
+                    lead, e = 1, e + 1
+    return "%s%d.%08d%s" % (sign, lead, dec, "E%d" % e if e else "")
+
+
 class Domain:
     """One lbmhip_domain handle plus its host mirrors (the reference's LBM_Domain, lbm.hpp:20-204)."""
 
@@ -216,7 +243,9 @@ class LBM:
         self.read_from_device()
         return self.write_host_to_vtk(name, path)
 
-    def write_host_to_vtk(self, name, path=""):
+    def write_host_to_vtk(self, name, path="", units=(1.0, 1.0, 1.0)):
+        """Legacy binary VTK like Memory_Container::write_vtk (lbm.hpp:298-340).  units = (m, kg, s) of one lattice unit
+        (units.hpp:9-13): spacing, origin and the values of rho, u and F are scaled to SI like the reference does."""
         a = getattr(self, name)
         if a is None:
             raise LbmHipError("field %s does not exist (FORCE_FIELD is off)" % name)
@@ -226,17 +255,18 @@ class LBM:
             path = (path or "./") + "%s-%09d.vtk" % (name, self.t)
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
         kind = "unsigned_char" if a.dtype == np.uint8 else "float"
-        def f6(v):  # the reference's to_string(float): d.dddddddd[E<exponent>] (utilities.hpp:2745-2754)
-            m, e = ("%.8E" % v).split("E")
-            return m + ("E%d" % int(e) if int(e) else "")
+        m, kg, sec = (float(v) for v in units)
+        f6 = float_string
         header = ("# vtk DataFile Version 3.0\nFluidX3D %s\nBINARY\nDATASET STRUCTURED_POINTS\nDIMENSIONS %d %d %d\nORIGIN %s %s %s\n"
                   "SPACING %s %s %s\nPOINT_DATA %d\nSCALARS data %s %d\nLOOKUP_TABLE default\n") % (
-            os.path.basename(path), Nx, Ny, Nz, f6(0.5 - 0.5 * Nx), f6(0.5 - 0.5 * Ny), f6(0.5 - 0.5 * Nz), f6(1.0), f6(1.0), f6(1.0), Nx * Ny * Nz, kind, d)
+            os.path.basename(path), Nx, Ny, Nz, f6(m * (0.5 - 0.5 * Nx)), f6(m * (0.5 - 0.5 * Ny)), f6(m * (0.5 - 0.5 * Nz)), f6(m), f6(m), f6(m), Nx * Ny * Nz, kind, d)
+        factor = np.float32({"rho": kg / m ** 3, "u": m / sec, "F": kg * m / sec ** 2}.get(name, 1.0))
         with open(path, "wb") as f:
             f.write(header.encode())
             for z in range(Nz):  # plane by plane: SoA -> interleaved, byte-swapped
                 plane = np.moveaxis(a[:, z], 0, -1) if d == 3 else a[z]
-                f.write(np.ascontiguousarray(plane).astype(">f4" if a.dtype == np.float32 else np.uint8).tobytes())
+                plane = np.ascontiguousarray(plane)
+                f.write((factor * plane).astype(">f4").tobytes() if a.dtype == np.float32 else plane.astype(np.uint8).tobytes())
         return path
 
     def get_tuning(self, key):

@@ -77,3 +77,30 @@ def test_misuse_is_reported_and_harmless(gpu):
     free1 = C.c_uint64()
     assert lib.lbmhip_device_memory(0, C.byref(free1), None) == 0
     assert abs(int(free1.value) - int(free0.value)) < (1 << 30)
+
+
+def test_halo_buffer_bookkeeping_and_mixed_domain_lists(gpu):
+    """Caller-owned staging buffers are given back with the library's own capacity, and the one-process exchange refuses
+    domain lists it cannot serve (a missing handle, blocks of different size) instead of copying wrong lengths."""
+    lib = cfd_amd.lib()
+    with cfd_amd.LBM((16, 16, 16), 0.01, D=(1, 1, 2), devices=[0, 0]) as lbm, cfd_amd.LBM((24, 16, 16), 0.01, D=(1, 1, 2), devices=[0, 0]) as other:
+        h = lbm.domains[0].h
+        p, own = C.c_void_p(), C.c_uint64()
+        assert lib.lbmhip_halo_buffer(h, 0, C.byref(p), C.byref(own)) == 0 and own.value == 16 * 16 * 20
+        import torch
+        big = [torch.empty(3 * own.value, dtype=torch.uint8, device="cuda:0") for _ in range(4)]
+        assert lib.lbmhip_halo_set_buffers(h, *[C.c_void_p(b.data_ptr()) for b in big], C.c_uint64(3 * own.value)) == 0
+        cap = C.c_uint64()
+        assert lib.lbmhip_halo_buffer(h, 0, C.byref(p), C.byref(cap)) == 0 and cap.value == 3 * own.value and p.value == big[0].data_ptr()
+        assert lib.lbmhip_halo_set_buffers(h, None, None, None, None, C.c_uint64(0)) == 0
+        assert lib.lbmhip_halo_buffer(h, 0, C.byref(p), C.byref(cap)) == 0 and cap.value == own.value and p.value != big[0].data_ptr()
+        last = lambda: lib.lbmhip_last_error().decode()
+        two = (C.c_void_p * 2)(lbm.domains[0].h, None)
+        assert lib.lbmhip_halo_exchange_local(two, 2, 0, 2) != 0 and "null" in last()
+        mixed = (C.c_void_p * 2)(lbm.domains[0].h, other.domains[1].h)
+        assert lib.lbmhip_halo_exchange_local(mixed, 2, 0, 2) != 0 and "differs from domain 0" in last()
+        setups_ok = (C.c_void_p * 2)(lbm.domains[0].h, lbm.domains[1].h)
+        for dom in lbm.domains:
+            assert lib.lbmhip_halo_pack(dom.h, 0, 2, C.c_uint64(0)) == 0
+        assert lib.lbmhip_halo_exchange_local(setups_ok, 2, 0, 2) == 0
+        lbm.sync()

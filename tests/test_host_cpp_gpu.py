@@ -46,7 +46,7 @@ def test_taylor_green_example_matches_python_mirror(gpu):
     assert err < 1e-4
     status = open(os.path.join(BIN, "export", "status-000000100.txt")).read()
     assert "Grid Resolution = 128 x 128 x 128 = 2097152\n" in status and "LBM Type = D3Q19 SRT (FP32/FP32)\n" in status
-    assert re.search(r"Average MLUPs/s = \d+\n", status) and "Kinematic Viscosity = 9.99999978E-3\n" in status and "Volume Force" not in status
+    assert re.search(r"Average MLUPs/s = \d+\n", status) and "Kinematic Viscosity = 1.00000000E-2\n" in status and "Volume Force" not in status
 
 
 def test_cavity_example_runs(gpu):
@@ -146,7 +146,7 @@ def test_python_vtk_writer_matches_the_cpp_host_layout(gpu, tmp_path):
             end = raw.index(b"LOOKUP_TABLE default\n") + len(b"LOOKUP_TABLE default\n")
             head = raw[:end].decode().splitlines()
             assert head[0] == "# vtk DataFile Version 3.0" and head[2] == "BINARY" and head[3] == "DATASET STRUCTURED_POINTS"
-            assert head[4] == "DIMENSIONS 24 16 8" and head[5] == "ORIGIN -1.15000000E1 -7.50000000 -3.50000000" and head[6] == "SPACING 1.00000000 1.00000000 1.00000000"
+            assert head[4] == "DIMENSIONS 24 16 8" and head[5] == "ORIGIN -1.14999998E1 -7.50000000 -3.50000000" and head[6] == "SPACING 1.00000000 1.00000000 1.00000000"
             assert head[7] == "POINT_DATA 3072" and head[8].startswith("SCALARS data ") and head[8].endswith(" %d" % comps)
             data = np.frombuffer(raw[end:], dtype=dt)
             want = getattr(lbm, name)
@@ -230,3 +230,32 @@ def test_cpp_slab_runner_over_rccl(gpu, storage):
     its own z-neighbour the overlapped exchange must reproduce the periodic lattice bit for bit."""
     out = run_example("slab_rccl", timeout=200, env=dict(LBM_SLAB_SELF="1", LBM_SLAB_N="128", LBM_SLAB_STEPS="60", LBM_SLAB_STORAGE=storage))
     assert "halo exchange over RCCL, overlapped" in out and "bit-identical" in out, out
+
+
+def test_export_files_equal_the_reference_format_fixture(gpu, tmp_path):
+    """The C++ host's VTK and status files against files worked out from the reference's format definition alone
+    (tests/golden/make_vtk_golden.py; FluidX3D-master/src/lbm.hpp:298-340, lbm.cpp:104-118, 1599-1643): byte for byte,
+    except the clock-dependent status lines, which must match the fixture's patterns."""
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vtk_fixture")
+    out = str(tmp_path) + "/"
+    run_example("vtk_fixture", env={"LBM_EXAMPLE_OUT": out})
+    for name in ("rho", "u", "flags", "F"):
+        file = "%s-000000000.vtk" % name
+        assert open(os.path.join(out, file), "rb").read() == open(os.path.join(golden, file), "rb").read(), file
+    got = open(os.path.join(out, "status-000000000.txt")).read().splitlines()
+    want = open(os.path.join(golden, "status-000000000.txt")).read().splitlines()
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        pattern = "".join(part if k % 2 else re.escape(part) for k, part in enumerate(re.split(r"<<<|>>>", w)))
+        assert re.fullmatch(pattern, g), (g, w)
+    # the Python mirror writes the same bytes
+    with cfd_amd.LBM((4, 3, 2), 0.125, features=("VOLUME_FORCE", "FORCE_FIELD"), f=(0.0, 0.0, 0.0009765625)) as lbm:
+        n = np.arange(24, dtype=np.float32).reshape(2, 3, 4)
+        lbm.rho[...] = 1.0 + n / 64.0
+        lbm.u[0], lbm.u[1], lbm.u[2] = n / 128.0, -n / 256.0, n / 512.0
+        lbm.flags[...] = ((np.arange(24) * 7) % 256).astype(np.uint8).reshape(2, 3, 4)
+        lbm.F[0], lbm.F[1], lbm.F[2] = n / 16.0, -n / 32.0, n / 8.0
+        if hasattr(lbm, "write_host_to_vtk"):
+            for name in ("rho", "u", "flags", "F"):
+                p = lbm.write_host_to_vtk(name, out + "py/", units=(2.0, 64.0, 0.5))
+                assert open(p, "rb").read() == open(os.path.join(golden, os.path.basename(p)), "rb").read(), name
