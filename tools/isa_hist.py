@@ -16,7 +16,7 @@ subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++
                check=True, stderr=subprocess.DEVNULL, cwd=tmp)
 asm = open(os.path.join(tmp, [f for f in os.listdir(tmp) if f.endswith("gfx950.s")][0])).read()
 feat = FEAT.replace("-", "n")
-name = ("_ZN3lbm9k_collideILi%sELi%sELi%sELi%sELb0EEEvNS_4ArgsE" % (Q, ST, COLL, feat)) if V == "1" else ("_ZN3lbm14k_collide_wideILi%sELi%sELi%sELi%sELi%sELi%sEEEvNS_4ArgsE" % (Q, ST, COLL, feat, V, P))
+name = ("_ZN3lbm9k_collideILi%sELi%sELi%sELi%sELb0EEEvNS_4ArgsE" % (Q, ST, COLL, feat)) if V == "1" else ("_ZN3lbm14k_collide_wideILi%sELi%sELi%sELi%sELi%sELi%sELb0EEEvNS_4ArgsE" % (Q, ST, COLL, feat, V, P))
 m = re.search(r"^%s:[^\n]*\n(.*?)\n\.Lfunc_end" % re.escape(name), asm, re.S | re.M)
 if not m:
     raise SystemExit("kernel %s not found" % name)
