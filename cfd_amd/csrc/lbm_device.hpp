@@ -264,23 +264,26 @@ template <int Q, class R> __device__ __forceinline__ void f_eq(R rho, R ux, R uy
 		feq[i+1] = fma_(wr, fma_(R(0.5f), fma_(cu, cu, c3), -cu), wm);
 	});
 }
-// kernel.cpp:1069-1094 (1 added last; momentum as alternating +/- chain over the pairs in ascending order)
+// kernel.cpp:1069-1094 (1 added last; momentum as alternating +/- chain over the pairs in ascending order).  The four
+// sums are independent chains; they are written pair by pair, side by side, so that consecutive instructions do not
+// depend on each other (each chain keeps its own order of additions, which is what fixes the bits).
 template <int Q, class R> __device__ __forceinline__ void rho_u(const R* f, R& rhon, R& uxn, R& uyn, R& uzn) {
 	R rho = f[0];
-	static_for<1, Q, 1>([&](auto I) { rho += f[I]; });
-	rho += 1.0f;
 	R m[3] = {R(0.0f), R(0.0f), R(0.0f)};
-	static_for<0, 3, 1>([&](auto K) {
-		constexpr int k = K;
-		bool started = false;
-		static_for<1, Q, 2>([&](auto I) {
-			constexpr int i = I, ck = dir<Q>(i, k);
+	bool started[3] = {false, false, false};
+	static_for<1, Q, 2>([&](auto I) {
+		constexpr int i = I;
+		rho += f[i];
+		static_for<0, 3, 1>([&](auto K) {
+			constexpr int k = K, ck = dir<Q>(i, k);
 			if constexpr (ck != 0) {
 				const R plus = ck > 0 ? f[i] : f[i+1], minus = ck > 0 ? f[i+1] : f[i];
-				if (!started) { m[k] = plus-minus; started = true; } else { m[k] = m[k]+plus; m[k] = m[k]-minus; }
+				if (!started[k]) { m[k] = plus-minus; started[k] = true; } else { m[k] = m[k]+plus; m[k] = m[k]-minus; }
 			}
 		});
+		rho += f[i+1];
 	});
+	rho += 1.0f;
 	rhon = rho; uxn = div_(m[0], rho); uyn = div_(m[1], rho); uzn = div_(m[2], rho);
 }
 __device__ __forceinline__ float clamp_c(float x) { return fminf(fmaxf(x, -0.57735027f), 0.57735027f); } // lbm.cpp:507
@@ -372,8 +375,13 @@ __device__ __forceinline__ void collide(R* f, const Feat feat, const uint8_t* bo
 				Fj = fma_(c_taup, Gj+Gi, c_taum*(Gj-Gi));
 			}
 			const R fi_ = f[i], fj_ = f[j], ei = feq[i], ej = feq[j];
-			const R ci = fma_(hwp, ei-fi_+ej-fj_, fma_(hwm, ei-ej-fi_+fj_, fi_+Fi));
-			const R cj = fma_(hwp, ej-fj_+ei-fi_, fma_(hwm, ej-ei-fj_+fi_, fj_+Fj));
+			// ci = hwp*(ei-fi+ej-fj) + (hwm*(ei-ej-fi+fj) + (fi+Fi)), cj likewise with i and j swapped (kernel.cpp:1640-1649); the four
+			// sums are written side by side, one addition of each at a time, so that neighbouring instructions are independent
+			R pi = ei-fi_, mi = ei-ej, pj = ej-fj_, mj = ej-ei;
+			pi = pi+ej; mi = mi-fi_; pj = pj+ei; mj = mj-fj_;
+			pi = pi-fj_; mi = mi+fj_; pj = pj-fi_; mj = mj+fi_;
+			const R ci = fma_(hwp, pi, fma_(hwm, mi, fi_+Fi));
+			const R cj = fma_(hwp, pj, fma_(hwm, mj, fj_+Fj));
 			f[i] = any_eq ? select_(eq_cell, ei, ci) : ci;
 			f[j] = any_eq ? select_(eq_cell, ej, cj) : cj;
 		});
