@@ -249,20 +249,28 @@ template <> struct Store<ST_FP16C> {
 };
 
 // ---------------------------------------------------------------------------------------------- moments, equilibrium, forcing
-// kernel.cpp:1010-1067 (shifted equilibrium, pair-symmetric nested fma)
+// kernel.cpp:1010-1067 (shifted equilibrium, pair-symmetric nested fma).  EqTerms holds what all directions share; the
+// equilibrium of one opposite pair is a separate function so that a collision without subgrid model can form it where it
+// is used (27 + 27 values live at the same time otherwise, which costs a wave of occupancy with 16-bit D3Q27 lattices).
+template <class R> struct EqTerms { R rho, rhom1, c3, ux3, uy3, uz3; };
+template <int Q, class R> __device__ __forceinline__ EqTerms<R> eq_terms(R rho, R ux, R uy, R uz) {
+	EqTerms<R> e;
+	e.rho = rho; e.rhom1 = rho-1.0f;
+	if constexpr (Q == 9) e.c3 = -3.0f*(ux*ux+uy*uy); else e.c3 = -3.0f*(ux*ux+uy*uy+uz*uz);
+	e.ux3 = ux*3.0f; e.uy3 = uy*3.0f; e.uz3 = uz*3.0f;
+	return e;
+}
+template <int Q, class R> __device__ __forceinline__ R f_eq_rest(const EqTerms<R>& e) { return weight<Q>(0)*fma_(e.rho, 0.5f*e.c3, e.rhom1); }
+template <int Q, int I, class R> __device__ __forceinline__ void f_eq_pair(const EqTerms<R>& e, R& feq_i, R& feq_j) { // directions I and I+1
+	const R cu = cdot<Q, I>(e.ux3, e.uy3, e.uz3);
+	const R wr = weight<Q>(I)*e.rho, wm = weight<Q>(I)*e.rhom1;
+	feq_i = fma_(wr, fma_(R(0.5f), fma_(cu, cu, e.c3), cu), wm);
+	feq_j = fma_(wr, fma_(R(0.5f), fma_(cu, cu, e.c3), -cu), wm);
+}
 template <int Q, class R> __device__ __forceinline__ void f_eq(R rho, R ux, R uy, R uz, R* feq) {
-	const R rhom1 = rho-1.0f;
-	R c3;
-	if constexpr (Q == 9) c3 = -3.0f*(ux*ux+uy*uy); else c3 = -3.0f*(ux*ux+uy*uy+uz*uz);
-	ux *= 3.0f; uy *= 3.0f; uz *= 3.0f;
-	feq[0] = weight<Q>(0)*fma_(rho, 0.5f*c3, rhom1);
-	static_for<1, Q, 2>([&](auto I) {
-		constexpr int i = I;
-		const R cu = cdot<Q, i>(ux, uy, uz);
-		const R wr = weight<Q>(i)*rho, wm = weight<Q>(i)*rhom1;
-		feq[i]   = fma_(wr, fma_(R(0.5f), fma_(cu, cu, c3), cu), wm);
-		feq[i+1] = fma_(wr, fma_(R(0.5f), fma_(cu, cu, c3), -cu), wm);
-	});
+	const EqTerms<R> e = eq_terms<Q>(rho, ux, uy, uz);
+	feq[0] = f_eq_rest<Q>(e);
+	static_for<1, Q, 2>([&](auto I) { f_eq_pair<Q, I>(e, feq[I], feq[I+1]); });
 }
 // kernel.cpp:1069-1094 (1 added last; momentum as alternating +/- chain over the pairs in ascending order).  The four
 // sums are independent chains; they are written pair by pair, side by side, so that consecutive instructions do not
@@ -295,6 +303,12 @@ template <int Q, int I, class R> __device__ __forceinline__ R forcing_term(R ux,
 	else return 9.0f*weight<Q>(I)*fma_(cdot<Q, I>(fx, fy, fz), cdot<Q, I>(ux, uy, uz)+0.33333334f, uF);
 }
 
+// feature-mask functors: compile-time constant or read from the launch arguments
+template <uint32_t MASK> struct StaticFeat { static constexpr uint32_t mask = MASK; __device__ __forceinline__ constexpr bool operator()(uint32_t bit) const { return (MASK&bit) != 0u; } };
+struct DynamicFeat { uint32_t mask; __device__ __forceinline__ bool operator()(uint32_t bit) const { return (mask&bit) != 0u; } };
+template <class Feat> struct fixed_features { static constexpr bool value = false; static constexpr uint32_t mask = 0u; };
+template <uint32_t MASK> struct fixed_features<StaticFeat<MASK>> { static constexpr bool value = true; static constexpr uint32_t mask = MASK; };
+
 // ---------------------------------------------------------------------------------------------- the collision of one cell (R = float) or of cells n, n+1 (R = float2v)
 // f[] holds the streamed-in DDFs; on return it holds the post-collision DDFs (kernel.cpp:1497-1651).
 // FEAT is the feature mask (compile-time when the kernel is specialised, run-time otherwise); bo[] and write_fields[] have one entry per cell.
@@ -326,45 +340,65 @@ __device__ __forceinline__ void collide(R* f, const Feat feat, const uint8_t* bo
 	for (int k = 0; k < W; k++) write_fields[k] = (FIELDS_ONLY || feat(F_UPDATE_FIELDS)) && !eq_cell[k];
 	if constexpr (FIELDS_ONLY) return;
 
-	R feq[Q];
-	f_eq<Q>(rhon, uxn, uyn, uzn, feq);
-	R w = R(a.w);
-	if (feat(F_SUBGRID)) { // Smagorinsky-Lilly (kernel.cpp:1597-1611)
-		const float tau0 = a.tau0; // = 1/w (kernel.cpp:1598)
-		R Hxx = R(0.0f), Hyy = R(0.0f), Hzz = R(0.0f), Hxy = R(0.0f), Hxz = R(0.0f), Hyz = R(0.0f);
-		static_for<1, Q, 1>([&](auto I) {
-			constexpr int i = I, cx = dir<Q>(i,0), cy = dir<Q>(i,1), cz = dir<Q>(i,2);
-			const R fneq = f[i]-feq[i];
-			if constexpr (cx != 0) Hxx += fneq;
-			if constexpr (cx*cy != 0) Hxy += cx*cy > 0 ? fneq : -fneq;
-			if constexpr (cy != 0) Hyy += fneq;
-			if constexpr (cx*cz != 0) Hxz += cx*cz > 0 ? fneq : -fneq;
-			if constexpr (cy*cz != 0) Hyz += cy*cz > 0 ? fneq : -fneq;
-			if constexpr (cz != 0) Hzz += fneq;
-		});
-		const R Qn = Hxx*Hxx+Hyy*Hyy+Hzz*Hzz+2.0f*(Hxy*Hxy+Hxz*Hxz+Hyz*Hyz);
-		w = div_(R(2.0f), tau0+sqrt_(tau0*tau0+div_(0.76421222f*sqrt_(Qn), rhon)));
-	}
 	const bool force = feat(F_VOLUME_FORCE);
 	R uF = R(0.0f);
 	if (force) { if constexpr (Q == 9) uF = -0.33333334f*fma_(uxn, fxn, uyn*fyn); else uF = -0.33333334f*fma_(uxn, fxn, fma_(uyn, fyn, uzn*fzn)); }
 	const bool any_eq = feat(F_EQUILIBRIUM_BOUNDARIES);
+
+	// With a fixed relaxation rate (no subgrid model, known at compile time) every pair's equilibrium is formed where the
+	// collision uses it; the subgrid model needs all of them first (its rate depends on the whole non-equilibrium part).
+	constexpr bool lazy = fixed_features<Feat>::value && (fixed_features<Feat>::mask&F_SUBGRID) == 0u;
+	const EqTerms<R> e = eq_terms<Q>(rhon, uxn, uyn, uzn);
+	R feq[lazy ? 1 : Q];
+	if constexpr (!lazy) {
+		feq[0] = f_eq_rest<Q>(e);
+		static_for<1, Q, 2>([&](auto I) { f_eq_pair<Q, I>(e, feq[I], feq[I+1]); });
+	}
+	auto eq_rest = [&]() -> R { if constexpr (lazy) return f_eq_rest<Q>(e); else return feq[0]; };
+	auto eq_pair = [&](auto I, R& ei, R& ej) { if constexpr (lazy) f_eq_pair<Q, I>(e, ei, ej); else { ei = feq[I]; ej = feq[I+1]; } };
+	R w = R(a.w);
+	if (feat(F_SUBGRID)) { // Smagorinsky-Lilly (kernel.cpp:1597-1611)
+		if constexpr (!lazy) {
+			const float tau0 = a.tau0; // = 1/w (kernel.cpp:1598)
+			R Hxx = R(0.0f), Hyy = R(0.0f), Hzz = R(0.0f), Hxy = R(0.0f), Hxz = R(0.0f), Hyz = R(0.0f);
+			static_for<1, Q, 1>([&](auto I) {
+				constexpr int i = I, cx = dir<Q>(i,0), cy = dir<Q>(i,1), cz = dir<Q>(i,2);
+				const R fneq = f[i]-feq[i];
+				if constexpr (cx != 0) Hxx += fneq;
+				if constexpr (cx*cy != 0) Hxy += cx*cy > 0 ? fneq : -fneq;
+				if constexpr (cy != 0) Hyy += fneq;
+				if constexpr (cx*cz != 0) Hxz += cx*cz > 0 ? fneq : -fneq;
+				if constexpr (cy*cz != 0) Hyz += cy*cz > 0 ? fneq : -fneq;
+				if constexpr (cz != 0) Hzz += fneq;
+			});
+			const R Qn = Hxx*Hxx+Hyy*Hyy+Hzz*Hzz+2.0f*(Hxy*Hxy+Hxz*Hxz+Hyz*Hyz);
+			w = div_(R(2.0f), tau0+sqrt_(tau0*tau0+div_(0.76421222f*sqrt_(Qn), rhon)));
+		}
+	}
 	if constexpr (COLL == COLL_SRT) { // kernel.cpp:1613-1622
 		const R c_tau = fma_(w, R(-0.5f), R(1.0f)), omw = 1.0f-w;
-		static_for<0, Q, 1>([&](auto I) {
+		auto relax = [&](auto I, const R eq) {
 			constexpr int i = I;
 			const R Fin = force ? forcing_term<Q, i>(uxn, uyn, uzn, fxn, fyn, fzn, uF)*c_tau : R(0.0f);
-			const R fc = fma_(omw, f[i], fma_(w, feq[i], Fin));
-			f[i] = any_eq ? select_(eq_cell, feq[i], fc) : fc;
+			const R fc = fma_(omw, f[i], fma_(w, eq, Fin));
+			f[i] = any_eq ? select_(eq_cell, eq, fc) : fc;
+		};
+		relax(std::integral_constant<int, 0>{}, eq_rest());
+		static_for<1, Q, 2>([&](auto I) {
+			R ei, ej;
+			eq_pair(I, ei, ej);
+			relax(I, ei);
+			relax(std::integral_constant<int, I+1>{}, ej);
 		});
 	} else { // TRT (kernel.cpp:1623-1651)
 		const R wp = w, wm = feat(F_SUBGRID) ? div_(R(1.0f), div_(R(0.1875f), div_(R(1.0f), w)-0.5f)+0.5f) : R(a.wm); // without subgrid w is the lattice constant
 		const R c_taup = fma_(wp, R(-0.25f), R(0.5f)), c_taum = fma_(wm, R(-0.25f), R(0.5f)), hwp = 0.5f*wp, hwm = 0.5f*wm;
 		{
+			const R e0 = eq_rest();
 			const R Fin0 = force ? forcing_term<Q, 0>(uxn, uyn, uzn, fxn, fyn, fzn, uF) : R(0.0f);
 			const R F0 = force ? fma_(c_taup, Fin0+Fin0, c_taum*(Fin0-Fin0)) : R(0.0f);
-			const R fc = fma_(hwp, feq[0]-f[0]+feq[0]-f[0], fma_(hwm, feq[0]-feq[0]-f[0]+f[0], f[0]+F0));
-			f[0] = any_eq ? select_(eq_cell, feq[0], fc) : fc;
+			const R fc = fma_(hwp, e0-f[0]+e0-f[0], fma_(hwm, e0-e0-f[0]+f[0], f[0]+F0));
+			f[0] = any_eq ? select_(eq_cell, e0, fc) : fc;
 		}
 		static_for<1, Q, 2>([&](auto I) {
 			constexpr int i = I, j = I+1;
@@ -374,7 +408,9 @@ __device__ __forceinline__ void collide(R* f, const Feat feat, const uint8_t* bo
 				Fi = fma_(c_taup, Gi+Gj, c_taum*(Gi-Gj));
 				Fj = fma_(c_taup, Gj+Gi, c_taum*(Gj-Gi));
 			}
-			const R fi_ = f[i], fj_ = f[j], ei = feq[i], ej = feq[j];
+			R ei, ej;
+			eq_pair(I, ei, ej);
+			const R fi_ = f[i], fj_ = f[j];
 			// ci = hwp*(ei-fi+ej-fj) + (hwm*(ei-ej-fi+fj) + (fi+Fi)), cj likewise with i and j swapped (kernel.cpp:1640-1649); the four
 			// sums are written side by side, one addition of each at a time, so that neighbouring instructions are independent
 			R pi = ei-fi_, mi = ei-ej, pj = ej-fj_, mj = ej-ei;
@@ -387,9 +423,5 @@ __device__ __forceinline__ void collide(R* f, const Feat feat, const uint8_t* bo
 		});
 	}
 }
-
-// feature-mask functors: compile-time constant or read from the launch arguments
-template <uint32_t MASK> struct StaticFeat { __device__ __forceinline__ constexpr bool operator()(uint32_t bit) const { return (MASK&bit) != 0u; } };
-struct DynamicFeat { uint32_t mask; __device__ __forceinline__ bool operator()(uint32_t bit) const { return (mask&bit) != 0u; } };
 
 } // namespace lbm
