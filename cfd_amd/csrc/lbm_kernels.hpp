@@ -144,7 +144,7 @@ template <class raw2, int V, class rvec> __device__ __forceinline__ void set_pai
 // arithmetic instructions, twice the live registers) - same bits either way.
 // FO = true is update_fields (kernel.cpp:1812-1894) with the same loads: moments only, rho/u written as whole vectors, no DDF stores (P = 1).
 template <int Q, int ST, int COLL, int FEAT, int V, int P, bool FO = false>
-__global__ __launch_bounds__(256) void k_collide_wide(const Args a) {
+__global__ __launch_bounds__(256, (P == 2 && V == 2 ? 3 : 1)) void k_collide_wide(const Args a) { // two cells in packed arithmetic: at least 3 waves per SIMD (at most 168 registers; 4 cells per lane would spill)
 	using S = Store<ST>;
 	using raw = typename S::raw;
 	static_assert(V == 2 || V == 4, "vectors of 2 or 4 cells");
