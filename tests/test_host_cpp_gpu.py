@@ -259,3 +259,28 @@ def test_export_files_equal_the_reference_format_fixture(gpu, tmp_path):
             for name in ("rho", "u", "flags", "F"):
                 p = lbm.write_host_to_vtk(name, out + "py/", units=(2.0, 64.0, 0.5))
                 assert open(p, "rb").read() == open(os.path.join(golden, os.path.basename(p)), "rb").read(), name
+
+
+@pytest.mark.parametrize("sig", ["SIGTERM", "SIGINT"])
+def test_stop_signal_ends_a_setup_that_ignores_running(gpu, sig):
+    """`while(lbm.get_t()<T) lbm.run(n);` without a look at `running` (legal in the reference, which does not intercept
+    these signals): the first SIGTERM / SIGINT stops the time stepping, and the process ends by itself after the grace
+    period with status 128+signal instead of spinning until it is killed."""
+    import signal
+    import time
+    p = subprocess.Popen([os.path.join(BIN, "stubborn")], stdin=subprocess.DEVNULL, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                         env=dict(os.environ, LBM_STOP_GRACE_MS="300"))
+    try:
+        deadline = time.time() + 60
+        line = b""
+        while b"started" not in line and time.time() < deadline:
+            line = p.stdout.readline()
+        assert b"started" in line
+        time.sleep(0.5)
+        assert p.poll() is None
+        signum = getattr(signal, sig)
+        p.send_signal(signum)
+        assert p.wait(timeout=10) == 128 + signum
+    finally:
+        if p.poll() is None:
+            p.kill()
