@@ -130,6 +130,9 @@ RAGGED = {
     "fp32_q27_x_halo_v2": dict(kw=dict(N=(44, 12, 12), nu=0.02, D=(2, 1, 1), Q=27, features=("MOVING_BOUNDARIES",)), setup="cavity"),
     "fp32_260x6x6": dict(kw=dict(N=(260, 6, 6), nu=0.02), setup="tgv"),
     "fp16s_1028x4x4_wide": dict(kw=dict(N=(1028, 4, 4), nu=0.02, storage="FP16S"), setup="tgv"),
+    # rows of several workgroups per stream, the lattice widths of the 2048^3 configuration
+    "fp16c_q27_2048x3x4_force": dict(kw=dict(N=(2048, 3, 4), nu=0.02, Q=27, storage="FP16C", features=("VOLUME_FORCE", "FORCE_FIELD"), f=(1e-5, 0.0, 0.0)), setup="channel"),
+    "fp32_1030x5x3_x_halo": dict(kw=dict(N=(2056, 5, 3), nu=0.02, D=(2, 1, 1), collision="TRT", features=("VOLUME_FORCE", "SUBGRID"), f=(1e-4, 0.0, 0.0)), setup="channel"),
     "q15_fp16s_3dom": dict(kw=dict(N=(24, 24, 12), nu=0.02, Q=15, D=(1, 3, 1), storage="FP16S"), setup="tgv"),
     # the feature sets of the reference's setup collection, which have kernel instances of their own
     "aero_fp16s_eq_sgs": dict(kw=dict(N=(40, 24, 20), nu=0.005, storage="FP16S", features=("EQUILIBRIUM_BOUNDARIES", "SUBGRID")), setup="inflow"),
