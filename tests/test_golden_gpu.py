@@ -108,6 +108,30 @@ def test_decomposition_invariance_at_scale(gpu):
     assert np.array_equal(rho0.view(np.uint32), rho2.view(np.uint32)) and np.array_equal(u0.view(np.uint32), u2.view(np.uint32))
 
 
+@pytest.mark.parametrize("name,kw,slabs", [
+    ("channel_512_rows", dict(N=(512, 512, 64), collision="TRT", features=("VOLUME_FORCE", "SUBGRID"), f=(2e-4, 0.0, 0.0)), 2),
+    ("channel_512_rows_fp16s", dict(N=(512, 512, 64), storage="FP16S", collision="TRT", features=("VOLUME_FORCE", "SUBGRID"), f=(2e-4, 0.0, 0.0)), 4),
+    ("q27_force_2048_rows", dict(N=(2048, 512, 16), Q=27, storage="FP16C", features=("VOLUME_FORCE", "FORCE_FIELD"), f=(1e-5, 0.0, 0.0)), 2),
+])
+def test_benchmark_configurations_do_not_depend_on_the_decomposition(gpu, name, kw, slabs):
+    """The channel and the D3Q27 force-field configuration of bench.py at their real row widths (512 and 2048 cells, several
+    workgroups per row, padded stream strides on the slabs): one domain and z-slabs must agree bit for bit, boundary force included."""
+    def run(D):
+        with cfd_amd.LBM(nu=0.01, D=D, **kw) as lbm:
+            setups.channel(lbm)
+            lbm.run(15)
+            if lbm.has_F:
+                lbm.update_force_field()
+            lbm.read_from_device()
+            assert np.isfinite(lbm.u).all() and float(np.abs(lbm.u).max()) > 1e-5
+            return lbm.rho.copy(), lbm.u.copy(), (lbm.F.copy() if lbm.has_F else None)
+    one, many = run((1, 1, 1)), run((1, 1, slabs))
+    assert np.array_equal(one[0].view(np.uint32), many[0].view(np.uint32))
+    assert np.array_equal(one[1].view(np.uint32), many[1].view(np.uint32))
+    if one[2] is not None:
+        assert np.array_equal(one[2].view(np.uint32), many[2].view(np.uint32)) and np.abs(one[2]).max() > 0
+
+
 # ---- mesh voxelizer on the GPU against the reference fixtures
 import os  # noqa: E402
 
