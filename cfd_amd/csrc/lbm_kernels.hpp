@@ -780,20 +780,25 @@ __global__ __launch_bounds__(256) void k_unvoxelize_mesh(const VoxelArgs v) {
 struct SumArgs { Args lat; float4* partial; uint32_t what; uint8_t marker; uint8_t skip_halo; float hx, hy, hz, cx, cy, cz; int32_t O[3]; };
 __global__ __launch_bounds__(256) void k_object_sum(const SumArgs s) {
 	const Args& a = s.lat;
-	const uint64_t plane = (uint64_t)a.Nx*a.Ny;
 	float4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-	for (uint64_t n = (uint64_t)blockIdx.x*blockDim.x+threadIdx.x; n < a.N; n += (uint64_t)gridDim.x*blockDim.x) {
-		const uint32_t z = (uint32_t)(n/plane), r = (uint32_t)(n%plane), y = r/a.Nx, x = r%a.Nx;
-		const bool halo = (a.hx && (x == 0u || x == a.Nx-1u)) || (a.hy && (y == 0u || y == a.Ny-1u)) || (a.hz && (z == 0u || z == a.Nz-1u));
-		if ((s.skip_halo && halo) || a.flags[n] != s.marker) continue;
+	// a workgroup takes whole lattice rows (row = y+z*Ny, wave-uniform), its lanes the cells of the row: no per-cell division
+	const uint32_t rows = a.Ny*a.Nz;
+	for (uint32_t row = blockIdx.x; row < rows; row += gridDim.x) {
+		const uint32_t z = row/a.Ny, y = row-z*a.Ny;
+		if (s.skip_halo && ((a.hy && (y == 0u || y == a.Ny-1u)) || (a.hz && (z == 0u || z == a.Nz-1u)))) continue;
+		const uint64_t row0 = (uint64_t)row*a.Nx;
 		// position() of kernel.cpp:834-836: coordinate + 0.5 - 0.5*size, then minus the rotation centre (kernel.cpp:1975)
-		const float px = (float)((int)x+s.O[0])+0.5f-s.hx-s.cx, py = (float)((int)y+s.O[1])+0.5f-s.hy-s.cy, pz = (float)((int)z+s.O[2])+0.5f-s.hz-s.cz;
-		if (s.what == 0u) { acc.x += px; acc.y += py; acc.z += pz; acc.w += 1.0f; }
-		else {
-			const float fx = a.F[n], fy = a.F[a.N+n], fz = a.F[2ull*a.N+n];
-			if (s.what == 1u) { acc.x += fx; acc.y += fy; acc.z += fz; }
-			else { acc.x += py*fz-pz*fy; acc.y += pz*fx-px*fz; acc.z += px*fy-py*fx; }
-			acc.w += 1.0f;
+		const float py = (float)((int)y+s.O[1])+0.5f-s.hy-s.cy, pz = (float)((int)z+s.O[2])+0.5f-s.hz-s.cz;
+		for (uint32_t x = threadIdx.x; x < a.Nx; x += blockDim.x) {
+			if ((s.skip_halo && a.hx && (x == 0u || x == a.Nx-1u)) || ld<uint8_t>(a.flags+row0, x) != s.marker) continue;
+			const float px = (float)((int)x+s.O[0])+0.5f-s.hx-s.cx;
+			if (s.what == 0u) { acc.x += px; acc.y += py; acc.z += pz; acc.w += 1.0f; }
+			else {
+				const float fx = ld<float>(a.F+row0, 4u*x), fy = ld<float>(a.F+a.N+row0, 4u*x), fz = ld<float>(a.F+2ull*a.N+row0, 4u*x);
+				if (s.what == 1u) { acc.x += fx; acc.y += fy; acc.z += fz; }
+				else { acc.x += py*fz-pz*fy; acc.y += pz*fx-px*fz; acc.z += px*fy-py*fx; }
+				acc.w += 1.0f;
+			}
 		}
 	}
 	for (int off = 32; off > 0; off >>= 1) { acc.x += __shfl_down(acc.x, off); acc.y += __shfl_down(acc.y, off); acc.z += __shfl_down(acc.z, off); acc.w += __shfl_down(acc.w, off); }
