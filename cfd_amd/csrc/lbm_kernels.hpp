@@ -423,13 +423,13 @@ __global__ __launch_bounds__(256, (P == 2 && V == 2 ? 3 : 1)) void k_collide_wid
 #ifdef LBM_SMALL_KERNELS // the one-cell-per-thread kernels are compiled once, in lbmhip.hip
 // ---------------------------------------------------------------------------------------------- one-cell-per-thread helpers
 struct Cell { uint32_t x, y, z; uint64_t n; bool valid; };
-__device__ __forceinline__ Cell cell_of_thread(const Args& a) { // grid = (ceil(Nx*Ny/block), Nz): one lattice plane per blockIdx.y
+__device__ __forceinline__ Cell cell_of_thread(const Args& a) { // grid = (xchunks*Ny, Nz), like the step kernels: y and z are wave-uniform, no 64-bit division
 	Cell c;
-	const uint64_t plane = (uint64_t)a.Nx*a.Ny, t = (uint64_t)blockIdx.x*blockDim.x+threadIdx.x;
-	c.valid = t < plane;
-	c.z = blockIdx.y;
-	c.x = (uint32_t)(t%a.Nx); c.y = (uint32_t)(t/a.Nx);
-	c.n = (uint64_t)c.z*plane+t;
+	const uint32_t chunk = blockIdx.x%a.xchunks;
+	c.y = blockIdx.x/a.xchunks; c.z = blockIdx.y;
+	c.x = chunk*blockDim.x+threadIdx.x;
+	c.valid = c.x < a.Nx;
+	c.n = ((uint64_t)c.z*a.Ny+c.y)*a.Nx+c.x;
 	return c;
 }
 __device__ __forceinline__ bool is_halo(const Args& a, const Cell& c) { // kernel.cpp:850-853

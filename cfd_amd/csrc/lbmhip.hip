@@ -573,9 +573,13 @@ template <int ST> __global__ __launch_bounds__(256) void k_convert_ddfs(const vo
 		default: switch (ST_) { case ST_FP32: { constexpr int Q = 27, ST = ST_FP32; CALL; } break; case ST_FP16S: { constexpr int Q = 27, ST = ST_FP16S; CALL; } break; default: { constexpr int Q = 27, ST = ST_FP16C; CALL; } break; } break; \
 	}
 
-static dim3 grid_cells(const lbmhip_domain* d, uint32_t block) { // one lattice plane per grid.y (stays below 2^32 work-items per dimension)
-	const uint64_t plane = (uint64_t)d->cfg.Nx*d->cfg.Ny;
-	return dim3((uint32_t)((plane+block-1u)/block), d->cfg.Nz);
+// one workgroup per lattice row chunk, rows and planes as grid.x and grid.y (at most 2^32-1 work-items per grid dimension);
+// sets a.xchunks and the workgroup size for the kernels that take one cell per lane
+static dim3 grid_rows(const lbmhip_domain* d, Args& a, dim3* block) {
+	const uint32_t lanes = std::min(256u, (d->cfg.Nx+63u)/64u*64u);
+	a.xchunks = (d->cfg.Nx+lanes-1u)/lanes;
+	*block = dim3(lanes);
+	return dim3(a.xchunks*d->cfg.Ny, d->cfg.Nz);
 }
 
 extern "C" {
@@ -584,11 +588,9 @@ int lbmhip_initialize(lbmhip_domain* d) {
 	NEED(d, "null domain");
 	DeviceGuard g(d->cfg.device);
 	Args a = make_args(d, 1u, 0.0f, 0.0f, 0.0f);
-	// one workgroup per lattice row chunk, rows and planes as grid.x and grid.y (at most 2^32-1 work-items per grid dimension)
-	const uint32_t block = std::min(256u, (d->cfg.Nx+63u)/64u*64u);
-	a.xchunks = (d->cfg.Nx+block-1u)/block;
-	NEED((uint64_t)a.xchunks*d->cfg.Ny*block < 0xFFFFFFFFull, "lattice too large for one launch");
-	DISPATCH_Q_ST((int)d->cfg.velocity_set, (int)d->cfg.storage, hipLaunchKernelGGL((k_initialize<Q, ST>), dim3(a.xchunks*d->cfg.Ny, d->cfg.Nz), dim3(block), 0, d->stream, a));
+	dim3 block;
+	const dim3 grid = grid_rows(d, a, &block);
+	DISPATCH_Q_ST((int)d->cfg.velocity_set, (int)d->cfg.storage, hipLaunchKernelGGL((k_initialize<Q, ST>), grid, block, 0, d->stream, a));
 	HIP_TRY(hipGetLastError());
 	return 0;
 }
@@ -609,8 +611,10 @@ int lbmhip_update_force_field(lbmhip_domain* d, uint64_t t) {
 	NEED(d, "null domain");
 	NEED(d->field[LBMHIP_FIELD_F], "update_force_field needs the FORCE_FIELD extension");
 	DeviceGuard g(d->cfg.device);
-	const Args a = make_args(d, t, 0.0f, 0.0f, 0.0f);
-	DISPATCH_Q_ST((int)d->cfg.velocity_set, (int)d->cfg.storage, hipLaunchKernelGGL((k_update_force_field<Q, ST>), grid_cells(d, 256u), dim3(256), 0, d->stream, a));
+	Args a = make_args(d, t, 0.0f, 0.0f, 0.0f);
+	dim3 block;
+	const dim3 grid = grid_rows(d, a, &block);
+	DISPATCH_Q_ST((int)d->cfg.velocity_set, (int)d->cfg.storage, hipLaunchKernelGGL((k_update_force_field<Q, ST>), grid, block, 0, d->stream, a));
 	HIP_TRY(hipGetLastError());
 	return 0;
 }
@@ -618,8 +622,10 @@ int lbmhip_reset_force_field(lbmhip_domain* d) {
 	NEED(d, "null domain");
 	NEED(d->field[LBMHIP_FIELD_F], "reset_force_field needs the FORCE_FIELD extension");
 	DeviceGuard g(d->cfg.device);
-	const Args a = make_args(d, 0u, 0.0f, 0.0f, 0.0f);
-	hipLaunchKernelGGL(k_reset_force_field, grid_cells(d, 256u), dim3(256), 0, d->stream, a);
+	Args a = make_args(d, 0u, 0.0f, 0.0f, 0.0f);
+	dim3 block;
+	const dim3 grid = grid_rows(d, a, &block);
+	hipLaunchKernelGGL(k_reset_force_field, grid, block, 0, d->stream, a);
 	HIP_TRY(hipGetLastError());
 	return 0;
 }
@@ -627,12 +633,14 @@ int lbmhip_update_moving_boundaries(lbmhip_domain* d) {
 	NEED(d, "null domain");
 	NEED(d->cfg.features&LBMHIP_MOVING_BOUNDARIES, "update_moving_boundaries needs the MOVING_BOUNDARIES extension");
 	DeviceGuard g(d->cfg.device);
-	const Args a = make_args(d, 0u, 0.0f, 0.0f, 0.0f);
+	Args a = make_args(d, 0u, 0.0f, 0.0f, 0.0f);
+	dim3 block;
+	const dim3 grid = grid_rows(d, a, &block);
 	switch (d->cfg.velocity_set) {
-		case 9: hipLaunchKernelGGL((k_update_moving_boundaries<9>), grid_cells(d, 256u), dim3(256), 0, d->stream, a); break;
-		case 15: hipLaunchKernelGGL((k_update_moving_boundaries<15>), grid_cells(d, 256u), dim3(256), 0, d->stream, a); break;
-		case 19: hipLaunchKernelGGL((k_update_moving_boundaries<19>), grid_cells(d, 256u), dim3(256), 0, d->stream, a); break;
-		default: hipLaunchKernelGGL((k_update_moving_boundaries<27>), grid_cells(d, 256u), dim3(256), 0, d->stream, a); break;
+		case 9: hipLaunchKernelGGL((k_update_moving_boundaries<9>), grid, block, 0, d->stream, a); break;
+		case 15: hipLaunchKernelGGL((k_update_moving_boundaries<15>), grid, block, 0, d->stream, a); break;
+		case 19: hipLaunchKernelGGL((k_update_moving_boundaries<19>), grid, block, 0, d->stream, a); break;
+		default: hipLaunchKernelGGL((k_update_moving_boundaries<27>), grid, block, 0, d->stream, a); break;
 	}
 	HIP_TRY(hipGetLastError());
 	return 0;
@@ -882,7 +890,9 @@ int lbmhip_unvoxelize_mesh(lbmhip_domain* d, uint8_t flag, const float* bounding
 	v.flag = flag;
 	v.O[0] = d->cfg.Ox; v.O[1] = d->cfg.Oy; v.O[2] = d->cfg.Oz;
 	for (int k = 0; k < 3; k++) { v.lo[k] = bounding_box[k]; v.hi[k] = bounding_box[3+k]; }
-	hipLaunchKernelGGL(k_unvoxelize_mesh, grid_cells(d, 256u), dim3(256), 0, d->stream, v);
+	dim3 block;
+	const dim3 grid = grid_rows(d, v.lat, &block);
+	hipLaunchKernelGGL(k_unvoxelize_mesh, grid, block, 0, d->stream, v);
 	HIP_TRY(hipGetLastError());
 	return 0;
 }
