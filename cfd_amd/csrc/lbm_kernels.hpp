@@ -668,6 +668,7 @@ __global__ __launch_bounds__(256) void k_halo_fields(const HaloArgs h, const uin
 struct VoxelArgs {
 	Args lat;
 	const float* p0; const float* p1; const float* p2; // 3 floats per triangle each
+	const float4* boxes; // per triangle: its extent in the two coordinates across the rays (see k_triangle_boxes), or nullptr: every ray tests every triangle
 	uint32_t triangles, direction;
 	int32_t O[3];
 	float lo[3], hi[3];  // bounding box of the mesh, widened by 2 cells (lbm.cpp:352-358)
@@ -686,13 +687,43 @@ __device__ __forceinline__ V3 cell_position(const VoxelArgs& v, uint32_t x, uint
 	const V3 off = {0.5f*(float)((int)a.Nx+2*v.O[0])-0.5f, 0.5f*(float)((int)a.Ny+2*v.O[1])-0.5f, 0.5f*(float)((int)a.Nz+2*v.O[2])-0.5f};
 	return v3add(p, off);
 }
+// The reference lets every ray test every triangle (kernel.cpp:2313-2328).  The test can only succeed for a ray that passes
+// through the triangle's projection, so a wave may skip a triangle whose projection lies clear of all its 64 rays - the
+// triangles that remain are visited in the same order with the same arithmetic, hence the same flags.  k_triangle_boxes
+// writes, per triangle, the extent of its projection in the two coordinates across the rays, widened by half a cell (the
+// rays are one cell apart; the rounding error of the intersection test is orders of magnitude smaller for the triangles
+// that get a box).  A triangle seen at less than ~3 degrees by the rays, or a sliver, gets an unbounded box and is never
+// skipped: there the computed barycentric coordinates are dominated by rounding and may accept rays far from the projection,
+// which the result must reproduce.
+__global__ __launch_bounds__(256) void k_triangle_boxes(const VoxelArgs v, float4* boxes) {
+	const uint32_t i = blockIdx.x*blockDim.x+threadIdx.x;
+	if (i >= v.triangles) return;
+	const V3 a0 = {v.p0[3u*i], v.p0[3u*i+1u], v.p0[3u*i+2u]}, a1 = {v.p1[3u*i], v.p1[3u*i+1u], v.p1[3u*i+2u]}, a2 = {v.p2[3u*i], v.p2[3u*i+1u], v.p2[3u*i+2u]};
+	const uint32_t dirn = v.direction;
+	const V3 dirv = {(float)(dirn == 0u), (float)(dirn == 1u), (float)(dirn == 2u)};
+	const V3 e1 = v3sub(a1, a0), e2 = v3sub(a2, a0);
+	const float g = v3dot(e1, v3cross(dirv, e2));
+	const float scale = sqrtf(v3dot(e1, e1))*sqrtf(v3dot(e2, e2));
+	const float inf = __builtin_huge_valf();
+	float4 box = {-inf, inf, -inf, inf};
+	if (fabsf(g) >= 0.05f*scale && scale < inf) { // well-conditioned; anything else (NaN included) keeps the unbounded box
+		const float pa[3] = {dirn == 0u ? a0.y : a0.x, dirn == 0u ? a1.y : a1.x, dirn == 0u ? a2.y : a2.x}; // first coordinate across the rays
+		const float pb[3] = {dirn == 2u ? a0.y : a0.z, dirn == 2u ? a1.y : a1.z, dirn == 2u ? a2.y : a2.z}; // second
+		box.x = fminf(fminf(pa[0], pa[1]), pa[2])-0.5f; box.y = fmaxf(fmaxf(pa[0], pa[1]), pa[2])+0.5f;
+		box.z = fminf(fminf(pb[0], pb[1]), pb[2])-0.5f; box.w = fmaxf(fmaxf(pb[0], pb[1]), pb[2])+0.5f;
+	}
+	boxes[i] = box;
+}
+__device__ __forceinline__ float wave_min(float x) { for (int m = 32; m > 0; m >>= 1) x = fminf(x, __shfl_xor(x, m)); return x; }
+__device__ __forceinline__ float wave_max(float x) { for (int m = 32; m > 0; m >>= 1) x = fmaxf(x, __shfl_xor(x, m)); return x; }
 template <int Q, int ST> __global__ __launch_bounds__(64) void k_voxelize_mesh(const VoxelArgs v) {
 	using S = Store<ST>; using raw = typename S::raw;
 	const Args& a = v.lat;
 	const uint32_t dirn = v.direction;
 	const uint32_t A = dirn == 0u ? a.Ny*a.Nz : dirn == 1u ? a.Nz*a.Nx : a.Nx*a.Ny;
-	const uint32_t fa = blockIdx.x*blockDim.x+threadIdx.x;
-	if (fa >= A) return;
+	const uint32_t fa_raw = blockIdx.x*blockDim.x+threadIdx.x;
+	const bool in_face = fa_raw < A;
+	const uint32_t fa = in_face ? fa_raw : A-1u; // lanes past the face stay for the wave reductions below and leave after them
 	const int Nd[3] = {(int)a.Nx, (int)a.Ny, (int)a.Nz};
 	uint32_t c[3];
 	const uint32_t start = (uint32_t)clampi((int)v.lo[dirn]-v.O[dirn], 0, Nd[dirn]-1);
@@ -704,19 +735,41 @@ template <int Q, int ST> __global__ __launch_bounds__(64) void k_voxelize_mesh(c
 	const bool outside = dirn == 0u ? (origin.y < v.lo[1] || origin.z < v.lo[2] || origin.y >= v.hi[1] || origin.z >= v.hi[2])
 	                   : dirn == 1u ? (origin.x < v.lo[0] || origin.z < v.lo[2] || origin.x >= v.hi[0] || origin.z >= v.hi[2])
 	                   : (origin.x < v.lo[0] || origin.y < v.lo[1] || origin.x >= v.hi[0] || origin.y >= v.hi[1]);
-	if (outside) return;
+	// the extent of this wave's rays in the two coordinates across them (only rays that take part count)
+	const bool active = in_face && !outside;
+	const float ra = dirn == 0u ? origin.y : origin.x, rb = dirn == 2u ? origin.y : origin.z;
+	const float big = __builtin_huge_valf();
+	const float wa0 = wave_min(active ? ra : big), wa1 = wave_max(active ? ra : -big), wb0 = wave_min(active ? rb : big), wb1 = wave_max(active ? rb : -big);
+	if (__ballot(active) == 0ull) return;
 	uint32_t ahead = 0u, behind = 0u;
 	uint16_t dist[64];
 	for (uint32_t i = 0u; i < 64u; i++) dist[i] = 0u;
-	for (uint32_t i = 0u; i < v.triangles; i++) {
-		const V3 a0 = {v.p0[3u*i], v.p0[3u*i+1u], v.p0[3u*i+2u]}, a1 = {v.p1[3u*i], v.p1[3u*i+1u], v.p1[3u*i+2u]}, a2 = {v.p2[3u*i], v.p2[3u*i+1u], v.p2[3u*i+2u]};
-		const V3 e1 = v3sub(a1, a0), e2 = v3sub(a2, a0), w = v3sub(origin, a0), h = v3cross(dirv, e2), q = v3cross(w, e1);
-		const float g = v3dot(e1, h), f = 1.0f/g, s = f*v3dot(w, h), tt = f*v3dot(dirv, q), d = f*v3dot(e2, q);
-		if (g != 0.0f && s >= 0.0f && s < 1.0f && tt >= 0.0f && s+tt < 1.0f) {
-			if (d > 0.0f) { if (ahead < 64u && d < 65536.0f) dist[ahead] = (uint16_t)d; ahead++; }
-			else behind++;
+	// Triangles in batches of 64: every lane (rays that do not take part included) fetches one box and compares it with the
+	// wave's extent, the votes form the list of triangles this wave has to test, and those are visited in ascending order.
+	const float4 nowhere = {big, -big, big, -big}; // the box of a triangle that is not there
+	float4 ahead_box = (v.boxes && threadIdx.x < v.triangles) ? v.boxes[threadIdx.x] : nowhere; // fetched one batch ahead of its use
+	for (uint32_t i0 = 0u; i0 < v.triangles; i0 += 64u) {
+		const uint32_t left = v.triangles-i0;
+		uint64_t todo = left >= 64u ? ~0ull : (1ull<<left)-1ull;
+		if (v.boxes) {
+			const float4 box = ahead_box;
+			ahead_box = (i0+64u+threadIdx.x < v.triangles) ? v.boxes[i0+64u+threadIdx.x] : nowhere;
+			todo = __ballot(!(box.y < wa0 || box.x > wa1 || box.w < wb0 || box.z > wb1));
+		}
+		while (todo != 0ull) {
+			const uint32_t i = i0+(uint32_t)__builtin_ctzll(todo);
+			todo &= todo-1ull;
+			if (!active) continue;
+			const V3 a0 = {v.p0[3u*i], v.p0[3u*i+1u], v.p0[3u*i+2u]}, a1 = {v.p1[3u*i], v.p1[3u*i+1u], v.p1[3u*i+2u]}, a2 = {v.p2[3u*i], v.p2[3u*i+1u], v.p2[3u*i+2u]};
+			const V3 e1 = v3sub(a1, a0), e2 = v3sub(a2, a0), w = v3sub(origin, a0), h = v3cross(dirv, e2), q = v3cross(w, e1);
+			const float g = v3dot(e1, h), f = 1.0f/g, s = f*v3dot(w, h), tt = f*v3dot(dirv, q), d = f*v3dot(e2, q);
+			if (g != 0.0f && s >= 0.0f && s < 1.0f && tt >= 0.0f && s+tt < 1.0f) {
+				if (d > 0.0f) { if (ahead < 64u && d < 65536.0f) dist[ahead] = (uint16_t)d; ahead++; }
+				else behind++;
+			}
 		}
 	}
+	if (!active) return;
 	const uint32_t kept = ahead < 64u ? ahead : 64u;
 	for (uint32_t i = 1u; i < kept; i++) { // insertion sort, ascending
 		const uint16_t val = dist[i]; uint32_t j = i;

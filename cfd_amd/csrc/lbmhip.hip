@@ -804,18 +804,24 @@ int lbmhip_halo_exchange_rccl(lbmhip_domain* d, void* comm, int what, int axis, 
 }
 
 // ---------------------------------------------------------------------------------------------- mesh voxelizer
-// Copies the three corner arrays (host) behind one another into `dev` (room for 9*triangles floats) and runs the kernel on the
-// handle's stream; returns when the flags (and, for a moving mesh, u and the DDFs) are written.
+// Device buffer of a mesh of T triangles, 13*T floats: T float4 boxes (k_triangle_boxes), then the three corner arrays.
+// Copies the corner arrays (host) in, works out the boxes and runs the kernel on the handle's stream; returns when the flags
+// (and, for a moving mesh, u and the DDFs) are written.
+static const size_t kMeshFloatsPerTriangle = 13u;
 static int voxelize_with_buffer(lbmhip_domain* d, float* dev, uint32_t direction, uint64_t t, uint8_t flag, const float* p0, const float* p1, const float* p2,
                                 uint32_t triangles, const float* bounding_box, const float* rotation_center, const float* linear_velocity, const float* rotational_velocity) {
-	const size_t bytes = (size_t)triangles*3u*sizeof(float);
-	hipError_t e = hipMemcpyAsync(dev, p0, bytes, hipMemcpyHostToDevice, d->stream);
-	if (e == hipSuccess) e = hipMemcpyAsync(dev+(size_t)triangles*3u, p1, bytes, hipMemcpyHostToDevice, d->stream);
-	if (e == hipSuccess) e = hipMemcpyAsync(dev+(size_t)triangles*6u, p2, bytes, hipMemcpyHostToDevice, d->stream);
+	const size_t T = triangles, bytes = T*3u*sizeof(float);
+	float* const corners = dev+4u*T;
+	hipError_t e = hipMemcpyAsync(corners, p0, bytes, hipMemcpyHostToDevice, d->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(corners+3u*T, p1, bytes, hipMemcpyHostToDevice, d->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(corners+6u*T, p2, bytes, hipMemcpyHostToDevice, d->stream);
 	if (e != hipSuccess) return fail("uploading the mesh failed: %s", hipGetErrorString(e));
 	VoxelArgs v;
 	v.lat = make_args(d, t, 0.0f, 0.0f, 0.0f);
-	v.p0 = dev; v.p1 = dev+(size_t)triangles*3u; v.p2 = dev+(size_t)triangles*6u;
+	v.p0 = corners; v.p1 = corners+3u*T; v.p2 = corners+6u*T;
+	const char* const cull_env = getenv("LBMHIP_VOXEL_CULL"); // 0: every ray tests every triangle, as in the reference (diagnostic, tests)
+	const bool cull = !(cull_env && cull_env[0] == '0');
+	v.boxes = cull ? reinterpret_cast<const float4*>(dev) : nullptr;
 	v.triangles = triangles; v.direction = direction; v.flag = flag;
 	v.O[0] = d->cfg.Ox; v.O[1] = d->cfg.Oy; v.O[2] = d->cfg.Oz;
 	for (int k = 0; k < 3; k++) {
@@ -824,6 +830,7 @@ static int voxelize_with_buffer(lbmhip_domain* d, float* dev, uint32_t direction
 		v.lin[k] = linear_velocity ? linear_velocity[k] : 0.0f;
 		v.rot[k] = rotational_velocity ? rotational_velocity[k] : 0.0f;
 	}
+	if (cull) hipLaunchKernelGGL(k_triangle_boxes, dim3((triangles+255u)/256u), dim3(256), 0, d->stream, v, reinterpret_cast<float4*>(dev));
 	const uint64_t A = face_area(d, (int)direction);
 	const dim3 grid((uint32_t)((A+63u)/64u)), block(64);
 	DISPATCH_Q_ST((int)d->cfg.velocity_set, (int)d->cfg.storage, hipLaunchKernelGGL((k_voxelize_mesh<Q, ST>), grid, block, 0, d->stream, v));
@@ -842,7 +849,7 @@ int lbmhip_voxelize_mesh(lbmhip_domain* d, uint32_t direction, uint64_t t, uint8
                          const float* bounding_box, const float* rotation_center, const float* linear_velocity, const float* rotational_velocity) {
 	if (voxelize_check(d, direction, p0, p1, p2, triangles, bounding_box)) return 1;
 	DeviceGuard g(d->cfg.device);
-	const size_t bytes = (size_t)triangles*9u*sizeof(float);
+	const size_t bytes = (size_t)triangles*kMeshFloatsPerTriangle*sizeof(float);
 	if (bytes > d->mesh_capacity) { // the domain keeps its triangle buffer: a mesh that moves is voxelized again every step (lbm.cpp:1645-1670)
 		HIP_TRY(hipStreamSynchronize(d->stream));
 		if (d->mesh) (void)hipFree(d->mesh);
@@ -856,7 +863,7 @@ int lbmhip_voxelize_mesh(lbmhip_domain* d, uint32_t direction, uint64_t t, uint8
 // The same call for callers that must not allocate device memory (code under graph capture, serving loops, harnesses that
 // forbid hipMalloc): the triangles are staged in a fixed array in the library's device image.  Every GPU holds its own copy
 // of the array at its own address; host code may only use that address, looked up once per device, never the array's name.
-static __device__ __align__(256) float scratch[9u*LBMHIP_STATIC_MESH_TRIANGLES];
+static __device__ __align__(256) float scratch[kMeshFloatsPerTriangle*LBMHIP_STATIC_MESH_TRIANGLES];
 static int scratch_address(int device, float** out) { // the device must be current
 	static std::mutex lock;
 	static float* address[64];

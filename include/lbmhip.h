@@ -152,7 +152,7 @@ int lbmhip_unvoxelize_mesh(lbmhip_domain* domain, uint8_t flag, const float* bou
  * harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same arguments and results as
  * lbmhip_voxelize_mesh, but the triangles are staged in a fixed buffer inside the library's device image instead of a
  * buffer owned by the domain: no hipMalloc / hipFree, ever.  Meshes of more than LBMHIP_STATIC_MESH_TRIANGLES triangles are
- * rejected with an error.  Each GPU holds one such buffer (4.5 MiB) for the life of the process and every domain on that GPU
+ * rejected with an error.  Each GPU holds one such buffer (6.5 MiB) for the life of the process and every domain on that GPU
  * shares it: calls that overlap on one GPU (two host threads, two domains with their own streams) race; calls one after the
  * other are safe, a call only reads the triangles it has copied in itself.  Complete when the call returns. */
 #define LBMHIP_STATIC_MESH_TRIANGLES 131072u

@@ -170,3 +170,45 @@ def test_voxelize_stl_then_run(gpu, tmp_path):
         lbm.read_from_device()
         assert np.isfinite(lbm.u).all() and (lbm.flags[solid] == 1).all()
         assert np.abs(lbm.u[0][~solid & ~face] - 0.075).max() > 1e-3  # the body disturbs the flow
+
+
+@pytest.mark.parametrize("direction", [0, 1, 2])
+@pytest.mark.parametrize("storage,moving", [("FP32", False), ("FP16S", True)])
+def test_voxelizer_triangle_boxes_change_nothing(gpu, monkeypatch, direction, storage, moving):
+    """The voxelizer skips, per wave, triangles whose projection lies clear of the wave's rays.  Against the plain loop over
+    every triangle (the reference's, LBMHIP_VOXEL_CULL=0) on triangle soups that are not even closed surfaces - tiny, huge,
+    degenerate, axis-aligned and nearly edge-on triangles - flags, u and DDFs must be the same bits."""
+    import ctypes as C
+    lib = cfd_amd.lib()
+    rng = np.random.RandomState(7 + direction)
+    N = (70, 45, 38)
+    T = 700
+    c = rng.uniform(2.0, 1.0, size=(T, 1, 3)) * 0 + rng.uniform([2, 2, 2], [N[0] - 2, N[1] - 2, N[2] - 2], size=(T, 3))[:, None, :]
+    size = np.choose(rng.randint(0, 4, T), [0.02, 0.7, 6.0, 40.0])[:, None, None]
+    tri = (c + size * rng.standard_normal((T, 3, 3))).astype(np.float32)
+    tri[::9, 1] = tri[::9, 0]                                   # degenerate: two corners coincide
+    tri[1::9, :, direction] = tri[1::9, :1, direction]          # faces across the rays, at one depth
+    other = (direction + 1) % 3
+    tri[2::9, :, other] = tri[2::9, :1, other]                  # seen exactly edge-on by the rays
+    tri[3::9, :, other] = tri[3::9, :1, other] + (1e-4 * rng.standard_normal((len(tri[3::9]), 3))).astype(np.float32)  # nearly edge-on
+    tri[4::9] = np.round(tri[4::9]) + 0.5                       # corners exactly on rays
+    p0, p1, p2 = (np.ascontiguousarray(tri[:, k].ravel()) for k in range(3))
+    box = np.concatenate([tri.reshape(-1, 3).min(0) - 2, tri.reshape(-1, 3).max(0) + 2]).astype(np.float32)
+    vel = (np.array([30.0, 20.0, 15.0], np.float32), np.array([0.01, 0.0, 0.02], np.float32), np.array([0.001, 0.003, 0.002], np.float32)) if moving else (None, None, None)
+    fp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+
+    def run(cull):
+        monkeypatch.setenv("LBMHIP_VOXEL_CULL", cull)
+        with cfd_amd.LBM(N, 0.01, D=(2, 1, 1), storage=storage) as lbm:
+            setups.taylor_green(lbm)
+            lbm.run(2)
+            for dom in lbm.domains:
+                cfd_amd.lbm.check(lib.lbmhip_voxelize_mesh(dom.h, C.c_uint32(direction), C.c_uint64(lbm.t + 1), C.c_uint8(1), fp(p0), fp(p1), fp(p2), C.c_uint32(T), fp(box),
+                                                           fp(vel[0]), fp(vel[1]), fp(vel[2])))
+            lbm._read_raw(("flags", "u"))
+            return lbm.flags.copy(), lbm.u.copy(), [dom.download_fi().copy() for dom in lbm.domains]
+    with_boxes, plain = run("1"), run("0")
+    assert np.array_equal(with_boxes[0], plain[0]) and (plain[0] == 1).sum() > 100
+    assert np.array_equal(with_boxes[1].view(np.uint32), plain[1].view(np.uint32))
+    for x, y in zip(with_boxes[2], plain[2]):
+        assert np.array_equal(x.view(np.uint8), y.view(np.uint8))
