@@ -354,6 +354,21 @@ int lbmhip_comm_join(lbmhip_domain* d) {
 	return 0;
 }
 
+int lbmhip_host_alloc(uint64_t bytes, void** host) {
+	NEED(host, "null argument");
+	*host = nullptr;
+	NEED(bytes > 0u, "lbmhip_host_alloc of 0 bytes");
+	void* p = nullptr;
+	const hipError_t e = hipHostMalloc(&p, (size_t)bytes, hipHostMallocPortable);
+	if (e != hipSuccess || !p) return fail("page-locked host memory of %llu bytes refused: %s", (unsigned long long)bytes, hipGetErrorString(e));
+	*host = p;
+	return 0;
+}
+int lbmhip_host_free(void* host) {
+	if (!host) return 0;
+	HIP_TRY(hipHostFree(host));
+	return 0;
+}
 int lbmhip_upload(lbmhip_domain* d, int field, const void* host, uint64_t offset, uint64_t bytes) {
 	NEED(d && host, "null argument");
 	NEED(field >= 0 && field < 5 && d->field[field], "field %d does not exist in this domain", field);

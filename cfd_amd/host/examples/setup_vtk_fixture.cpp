@@ -12,6 +12,7 @@ void main_setup() {
 		lbm.flags[n] = (uchar)((n*7ull)%256ull);
 		lbm.F.x[n] = v/16.0f; lbm.F.y[n] = -v/32.0f; lbm.F.z[n] = v/8.0f;
 	}
+	println("pinned "+to_string((uint)lbm.lbm_domain[0]->rho.is_pinned())); // host copies in page-locked memory unless LBM_PINNED=0
 	const char* out = std::getenv("LBM_EXAMPLE_OUT");
 	const string path = out ? string(out) : get_exe_path()+"export/";
 	lbm.rho.write_host_to_vtk(path);

@@ -21,21 +21,46 @@ string default_filename(const string& name, const string& extension, const ulong
 uint lbm_features();                        // extension bits selected in defines.hpp
 
 // host mirror of one device field of one domain (the part of Memory<T>, opencl.hpp:350-612, that LBM uses)
+// Host copy of one device field (opencl.hpp:356-372, 505-526).  The buffer is page-locked when the system grants it (the
+// transfers then run at the full rate of the host link), ordinary memory otherwise; LBM_PINNED=0 keeps it ordinary.
 template <typename T> class Memory {
 	lbmhip_domain* domain = nullptr;
 	int field = 0;
 	ulong N = 0ull;
 	uint d = 1u;
-	vector<T> host;
+	T* host = nullptr;
+	bool pinned = false;
+	ulong count() const { return N*(ulong)d; }
+	void release() {
+		if (host) { if (pinned) lbmhip_host_free(host); else std::free(host); }
+		host = nullptr; pinned = false;
+	}
 public:
 	Memory() {}
-	Memory(lbmhip_domain* domain, const int field, const ulong N, const uint dimensions, const T value = (T)0) : domain(domain), field(field), N(N), d(dimensions), host(N*(ulong)dimensions, value) {}
-	T* data() { return host.data(); }
+	Memory(lbmhip_domain* domain, const int field, const ulong N, const uint dimensions, const T value = (T)0) : domain(domain), field(field), N(N), d(dimensions) {
+		if (count() == 0ull) return;
+		const char* env = std::getenv("LBM_PINNED");
+		void* p = nullptr;
+		if (!(env && env[0] == '0') && lbmhip_host_alloc(count()*sizeof(T), &p) == 0) { host = static_cast<T*>(p); pinned = true; }
+		else host = static_cast<T*>(std::malloc(count()*sizeof(T)));
+		if (!host) print_error("Host memory of "+to_string((ulong)(count()*sizeof(T)/1048576ull))+" MB could not be allocated.");
+		std::fill(host, host+count(), value);
+	}
+	Memory(const Memory&) = delete;
+	Memory& operator=(const Memory&) = delete;
+	Memory(Memory&& m) noexcept { *this = std::move(m); }
+	Memory& operator=(Memory&& m) noexcept {
+		if (this != &m) { release(); domain = m.domain; field = m.field; N = m.N; d = m.d; host = m.host; pinned = m.pinned; m.host = nullptr; m.pinned = false; m.N = 0ull; }
+		return *this;
+	}
+	~Memory() { release(); }
+	T* data() { return host; }
 	ulong length() const { return N; }
 	uint dimensions() const { return d; }
-	void reset(const T value = (T)0) { std::fill(host.begin(), host.end(), value); write_to_device(); }
-	void read_from_device() { if (lbmhip_download(domain, field, host.data(), 0ull, host.size()*sizeof(T))) print_error(lbmhip_last_error()); }
-	void write_to_device() { if (lbmhip_upload(domain, field, host.data(), 0ull, host.size()*sizeof(T))) print_error(lbmhip_last_error()); }
+	bool is_pinned() const { return pinned; }
+	void reset(const T value = (T)0) { std::fill(host, host+count(), value); write_to_device(); }
+	void read_from_device() { if (count() && lbmhip_download(domain, field, host, 0ull, count()*sizeof(T))) print_error(lbmhip_last_error()); }
+	void write_to_device() { if (count() && lbmhip_upload(domain, field, host, 0ull, count()*sizeof(T))) print_error(lbmhip_last_error()); }
 };
 
 class LBM_Domain { // one lattice block on one GPU (lbm.hpp:20-204)

@@ -87,13 +87,18 @@ def test_halo_buffer_bookkeeping_and_mixed_domain_lists(gpu):
         h = lbm.domains[0].h
         p, own = C.c_void_p(), C.c_uint64()
         assert lib.lbmhip_halo_buffer(h, 0, C.byref(p), C.byref(own)) == 0 and own.value == 16 * 16 * 20
-        import torch
-        big = [torch.empty(3 * own.value, dtype=torch.uint8, device="cuda:0") for _ in range(4)]
-        assert lib.lbmhip_halo_set_buffers(h, *[C.c_void_p(b.data_ptr()) for b in big], C.c_uint64(3 * own.value)) == 0
+        # caller-owned device memory: the (larger) staging buffers of another domain stand in for it
+        big, big_cap = [], C.c_uint64()
+        for k in range(4):
+            q = C.c_void_p()
+            assert lib.lbmhip_halo_buffer(other.domains[0].h, k, C.byref(q), C.byref(big_cap)) == 0
+            big.append(q.value)
+        assert big_cap.value == 24 * 16 * 20 > own.value
+        assert lib.lbmhip_halo_set_buffers(h, *[C.c_void_p(b) for b in big], big_cap) == 0
         cap = C.c_uint64()
-        assert lib.lbmhip_halo_buffer(h, 0, C.byref(p), C.byref(cap)) == 0 and cap.value == 3 * own.value and p.value == big[0].data_ptr()
+        assert lib.lbmhip_halo_buffer(h, 0, C.byref(p), C.byref(cap)) == 0 and cap.value == big_cap.value and p.value == big[0]
         assert lib.lbmhip_halo_set_buffers(h, None, None, None, None, C.c_uint64(0)) == 0
-        assert lib.lbmhip_halo_buffer(h, 0, C.byref(p), C.byref(cap)) == 0 and cap.value == own.value and p.value != big[0].data_ptr()
+        assert lib.lbmhip_halo_buffer(h, 0, C.byref(p), C.byref(cap)) == 0 and cap.value == own.value and p.value != big[0]
         last = lambda: lib.lbmhip_last_error().decode()
         two = (C.c_void_p * 2)(lbm.domains[0].h, None)
         assert lib.lbmhip_halo_exchange_local(two, 2, 0, 2) != 0 and "null" in last()

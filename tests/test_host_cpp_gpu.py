@@ -238,10 +238,12 @@ def test_export_files_equal_the_reference_format_fixture(gpu, tmp_path):
     except the clock-dependent status lines, which must match the fixture's patterns."""
     golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vtk_fixture")
     out = str(tmp_path) + "/"
-    run_example("vtk_fixture", env={"LBM_EXAMPLE_OUT": out})
-    for name in ("rho", "u", "flags", "F"):
-        file = "%s-000000000.vtk" % name
-        assert open(os.path.join(out, file), "rb").read() == open(os.path.join(golden, file), "rb").read(), file
+    for pinned in ("1", "0"):  # host copies of the fields in page-locked or in ordinary memory: the same files
+        text = run_example("vtk_fixture", env={"LBM_EXAMPLE_OUT": out, "LBM_PINNED": pinned})
+        assert "pinned " + pinned in text
+        for name in ("rho", "u", "flags", "F"):
+            file = "%s-000000000.vtk" % name
+            assert open(os.path.join(out, file), "rb").read() == open(os.path.join(golden, file), "rb").read(), file
     got = open(os.path.join(out, "status-000000000.txt")).read().splitlines()
     want = open(os.path.join(golden, "status-000000000.txt")).read().splitlines()
     assert len(got) == len(want)
