@@ -25,7 +25,6 @@ import subprocess
 import sys
 import time
 
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

@@ -1,9 +1,7 @@
 """Diagnostic: update_fields and initialize at 512^3 D3Q19 over cells per lane and residency caps (GPU needed)."""
 import ctypes as C
-import os
 import sys
 
-import numpy as np
 
 sys.path.insert(0, ".")
 import cfd_amd

@@ -1,4 +1,5 @@
-import ctypes as C, sys, time
+"""Diagnostic: upload and download rate of a 1.6 GB field from and to pageable and page-locked host memory (GPU needed)."""
+import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
 import cfd_amd

@@ -3,7 +3,6 @@ import os
 import sys
 import time
 
-import numpy as np
 
 sys.path.insert(0, ".")
 import cfd_amd
