@@ -603,6 +603,24 @@ int lbmhip_initialize(lbmhip_domain* d) {
 	NEED(d, "null domain");
 	DeviceGuard g(d->cfg.device);
 	Args a = make_args(d, 1u, 0.0f, 0.0f, 0.0f);
+	const char* const pairs_env = getenv("LBMHIP_INIT_PAIRS"); // 0: one cell per lane also with 16-bit DDFs (diagnostic)
+	if (d->cfg.storage != LBMHIP_FP32 && d->cfg.Nx%2u == 0u && !(pairs_env && pairs_env[0] == '0')) { // two cells per lane: dword stores
+		const uint32_t lanes_per_row = d->cfg.Nx/2u, lanes = std::min(256u, (lanes_per_row+63u)/64u*64u);
+		a.xchunks = (lanes_per_row+lanes-1u)/lanes;
+		const dim3 grid(a.xchunks*d->cfg.Ny, d->cfg.Nz), block(lanes);
+		switch (d->cfg.velocity_set*4u+d->cfg.storage) {
+			case 9u*4u+1u: hipLaunchKernelGGL((k_initialize_pairs<9, ST_FP16S>), grid, block, 0, d->stream, a); break;
+			case 9u*4u+2u: hipLaunchKernelGGL((k_initialize_pairs<9, ST_FP16C>), grid, block, 0, d->stream, a); break;
+			case 15u*4u+1u: hipLaunchKernelGGL((k_initialize_pairs<15, ST_FP16S>), grid, block, 0, d->stream, a); break;
+			case 15u*4u+2u: hipLaunchKernelGGL((k_initialize_pairs<15, ST_FP16C>), grid, block, 0, d->stream, a); break;
+			case 19u*4u+1u: hipLaunchKernelGGL((k_initialize_pairs<19, ST_FP16S>), grid, block, 0, d->stream, a); break;
+			case 19u*4u+2u: hipLaunchKernelGGL((k_initialize_pairs<19, ST_FP16C>), grid, block, 0, d->stream, a); break;
+			case 27u*4u+1u: hipLaunchKernelGGL((k_initialize_pairs<27, ST_FP16S>), grid, block, 0, d->stream, a); break;
+			default: hipLaunchKernelGGL((k_initialize_pairs<27, ST_FP16C>), grid, block, 0, d->stream, a); break;
+		}
+		HIP_TRY(hipGetLastError());
+		return 0;
+	}
 	dim3 block;
 	const dim3 grid = grid_rows(d, a, &block);
 	DISPATCH_Q_ST((int)d->cfg.velocity_set, (int)d->cfg.storage, hipLaunchKernelGGL((k_initialize<Q, ST>), grid, block, 0, d->stream, a));
