@@ -7,7 +7,9 @@ N > 1 runs one rank per GPU over RCCL.  Started under torch.distributed.run (WOR
 started plainly it launches the N ranks itself (before anything touches the GPU), forwards rank 0's JSON line and exits
 with their status.
 
-Configurations (a step = one stream_collide pass over the whole lattice + the DDF halo exchange between z-slabs):
+Configurations (a step = one stream_collide pass over the whole lattice + the DDF halo exchange between z-slabs; on one
+GPU the K timed steps go to the library in one lbmhip_stream_collide_steps call, which runs a single periodic domain of the
+headline kind two steps per launch - the same bits as K single launches):
   tgv        periodic Taylor-Green vortex, D3Q19 SRT, 512^3 cells per GPU, weak scaling - the configuration the headline
              metric is quoted on (153 algorithmic bytes per cell and step with FP32 DDFs)
   channel    force-driven channel with extruded pillars (seed 42), walls in y and z, D3Q19 TRT + SUBGRID + VOLUME_FORCE,
@@ -139,6 +141,7 @@ def main():
     ap.add_argument("--storage", default=None, choices=["FP32", "FP16S", "FP16C"], help="DDF storage (default: the configuration's own)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--no-fuse", action="store_true", help="one launch per step also where the library would run two steps per launch")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse several ranks on one GPU)")
     a = ap.parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -189,20 +192,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if a.no_fuse:
+        check(lib.lbmhip_set_tuning(lbm.ops.dom.h, b"fuse", 0))
     # untimed: the library tries its launch geometries on the first full-lattice launches and keeps the fastest
-    tuned = C.c_int(0)
+    # (a lattice whose steps are paired needs no search: the odd step of a call at most runs the single-step kernel)
+    tuned, fused = C.c_int(0), C.c_int(0)
     for _ in range(TUNE_STEPS // 20):
         lbm.run(20)
         check(lib.lbmhip_get_tuning(lbm.ops.dom.h, b"tuned", C.byref(tuned)))
-        if tuned.value:
+        check(lib.lbmhip_get_tuning(lbm.ops.dom.h, b"fused", C.byref(fused)))
+        if tuned.value or fused.value:
             break
     lbm.run(a.warmup)
     barrier()
     ms_events = C.c_float()
     t0 = time.perf_counter()
     check(lib.lbmhip_timer_start(lbm.ops.dom.h))          # HIP events on the stream the kernels are launched on
-    for _ in range(a.steps):
-        lbm.do_time_step()
+    if world == 1:
+        lbm.run(a.steps)                                  # one lbmhip_stream_collide_steps call for the K steps
+    else:
+        for _ in range(a.steps):
+            lbm.do_time_step()
     check(lib.lbmhip_timer_stop(lbm.ops.dom.h, C.byref(ms_events)))
     barrier()
     own_seconds = time.perf_counter() - t0
@@ -221,17 +231,22 @@ def main():
     B = lib.lbmhip_bandwidth_bytes_per_cell(cfg["Q"], STORAGE[a.storage], mask_bits)
     if rank == 0:
         geometry = {}
-        for key in ("tuned", "cells_per_thread", "cells_together", "blocks_per_cu", "block", "jit"):
+        check(lib.lbmhip_get_tuning(lbm.ops.dom.h, b"fused", C.byref(fused)))  # of the timed call
+        keys = ("pair_lag", "pair_blocks_per_cu") if fused.value else ("tuned", "cells_per_thread", "cells_together", "blocks_per_cu", "block", "jit")
+        for key in keys:
             v = C.c_int(); check(lib.lbmhip_get_tuning(lbm.ops.dom.h, key.encode(), C.byref(v))); geometry[key] = v.value
+        steps_per_launch = 2 if fused.value else 1
+        geometry["steps_per_launch"] = steps_per_launch
         per_gpu = "%dx%dx%d" % (N[0], N[1], N[2] // world)
         if a.config == "tgv" and N[0] == N[1] == N[2] // world:
             workload = "taylor_green_%d^3_per_gpu_d3q19_srt_%s" % (N[0], a.storage.lower())
         else:
             workload = "%s_%s_per_gpu_d3q%d_%s_%s%s" % (cfg["label"], per_gpu, cfg["Q"], cfg["collision"].lower(), a.storage.lower(),
                                                          "".join("_" + f.lower() for f in cfg["features"]))
-        kernel_ms = ms_events.value / a.steps               # this rank's launches per step (N=1: exactly one stream_collide launch)
-        achieved = B * cells_rank / (kernel_ms * 1e-3) / 1e9
-        traffic, traffic_source = measured_traffic(workload) if world == 1 else (None, None)
+        # N=1: the timed region is a.steps / steps_per_launch launches of one kernel (an odd a.steps ends with one single-step launch)
+        kernel_ms = ms_events.value / a.steps * steps_per_launch   # per launch
+        achieved = B * cells_rank * steps_per_launch / (kernel_ms * 1e-3) / 1e9
+        traffic, traffic_source = measured_traffic(workload + ("_2steps" if fused.value else "")) if world == 1 else (None, None)
         headline = a.config == "tgv" and a.storage == "FP32" and N[0] == N[1] == 512 and N[2] == 512 * world
         out = {
             "metric": "MLUPs/s", "value": round(value, 1), "unit": "MLUPs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -245,7 +260,8 @@ def main():
             "timed_region_s": round(seconds, 4),
             "per_rank_mlups": [round(cells_rank * a.steps / s / 1e6, 1) for s in per_rank],
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "traffic_source": traffic_source, "kernel": "stream_collide", "kernel_ms": round(kernel_ms, 4)},
+                         "traffic": traffic, "traffic_source": traffic_source, "kernel": "stream_collide, two steps per launch (k_collide_pair)" if fused.value else "stream_collide",
+                         "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": B * cells_rank * steps_per_launch},
         }
         if seconds < SHORT_REGION_S:
             out["short_timed_region"] = True

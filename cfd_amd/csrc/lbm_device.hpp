@@ -121,6 +121,26 @@ template <class T, class B> __device__ __forceinline__ void st(B* uniform_base, 
 	*reinterpret_cast<W*>(reinterpret_cast<char*>(uniform_base)+byte_offset) = __builtin_bit_cast(W, value);
 }
 
+// The same accesses at agent scope, for data handed from one workgroup to another inside one launch (k_collide_pair): a
+// store that is written through to memory instead of staying dirty in the L2 of the storing XCD, and a load that does not
+// take its data from the CU's L1.  Elements of 1, 2 or 4 bytes.
+enum : int { MEM_PLAIN = 0, MEM_STORE_THROUGH = 1, MEM_LOAD_COHERENT = 2 };
+template <class T, int MEM, class B> __device__ __forceinline__ T ld_ddf(const B* uniform_base, const uint32_t byte_offset) {
+	if constexpr (MEM == MEM_LOAD_COHERENT) {
+		typedef typename bytes_of<sizeof(T)>::type W;
+		static_assert(sizeof(T) <= 4, "agent-scope accesses move single elements");
+		W* p = reinterpret_cast<W*>(const_cast<char*>(reinterpret_cast<const char*>(uniform_base))+byte_offset);
+		return __builtin_bit_cast(T, __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+	} else return ld<T>(uniform_base, byte_offset);
+}
+template <int MEM, class T, class B> __device__ __forceinline__ void st_ddf(B* uniform_base, const uint32_t byte_offset, const T value) {
+	if constexpr (MEM == MEM_STORE_THROUGH) {
+		typedef typename bytes_of<sizeof(T)>::type W;
+		static_assert(sizeof(T) <= 4, "agent-scope accesses move single elements");
+		__hip_atomic_store(reinterpret_cast<W*>(reinterpret_cast<char*>(uniform_base)+byte_offset), __builtin_bit_cast(W, value), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	} else st(uniform_base, byte_offset, value);
+}
+
 // c_i . (a,b,c) with zero components skipped, accumulated in x,y,z order
 template <int Q, int I, class R> __device__ __forceinline__ R cdot(R a, R b, R c) {
 	constexpr int cx = dir<Q>(I,0), cy = dir<Q>(I,1), cz = dir<Q>(I,2);

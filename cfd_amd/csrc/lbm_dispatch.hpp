@@ -25,6 +25,15 @@ hipError_t launch_fields_wide(const Args& a, dim3 grid, dim3 block, uint32_t lds
 	return hipGetLastError();
 }
 
+// two time steps in one launch (k_collide_pair); nullptr when the configuration has no compiled instance
+typedef hipError_t (*pair_launch_fn)(const Args&, const PairArgs&, dim3 grid, dim3 block, uint32_t lds_bytes, hipStream_t stream);
+template <int Q, int ST, int COLL, int FEAT>
+hipError_t launch_collide_pair(const Args& a, const PairArgs& p, dim3 grid, dim3 block, uint32_t lds_bytes, hipStream_t stream) {
+	hipLaunchKernelGGL((k_collide_pair<Q, ST, COLL, FEAT>), grid, block, lds_bytes, stream, a, p);
+	return hipGetLastError();
+}
+pair_launch_fn select_collide_pair(int Q, int ST, int COLL, int FEAT);
+
 // FEAT < 0 selects the instance that reads the feature mask at run time; FO = update_fields (always run-time features)
 // V = cells per lane; P = 2 selects the instance that collides two cells at a time in packed arithmetic (V = 2 or 4 only)
 template <int Q, int ST, int COLL, int FEAT> collide_launch_fn pick_v(int V, int P) {

@@ -31,12 +31,13 @@ template <int Q> __device__ __forceinline__ void apply_moving_boundaries(float* 
 // ---------------------------------------------------------------------------------------------- stream_collide / update_fields, one cell per lane
 // FluidX3D-master/src/kernel.cpp:1470-1654 (FIELDS_ONLY=false) and 1812-1894 (FIELDS_ONLY=true).
 // FEAT >= 0: features fixed at compile time; FEAT < 0: taken from Args::features.
-template <int Q, int ST, int COLL, int FEAT, bool FIELDS_ONLY>
-__global__ __launch_bounds__(256) void k_collide(const Args a) {
+// collide_row is the work of one workgroup: the x-chunk `chunk` of lattice row (y, z).  MEM chooses how the DDFs move
+// (plain accesses, or the agent-scope forms k_collide_pair needs); flags, rho, u and F always move plainly.
+// HAVE_FLAG: the caller has loaded the lane's flag byte already (`flag`).
+template <int Q, int ST, int COLL, int FEAT, bool FIELDS_ONLY, int MEM = MEM_PLAIN, bool HAVE_FLAG = false>
+__device__ __forceinline__ void collide_row(const Args& a, const uint32_t chunk, const uint32_t y, const uint32_t z, const uint32_t flag = 0u) {
 	using S = Store<ST>;
 	using raw = typename S::raw;
-	// grid = (xchunks*Ny, planes): a launch may not exceed 2^32 work-items per grid dimension, and 1600^3 lattices do
-	const uint32_t chunk = blockIdx.x%a.xchunks, y = blockIdx.x/a.xchunks, z = a.z0+blockIdx.y;
 	if (a.hy && (y == 0u || y == a.Ny-1u)) return;
 	const uint32_t x = chunk*blockDim.x+threadIdx.x;
 	if (x >= a.Nx) return;
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(256) void k_collide(const Args a) {
 	// stays to write the bits it owns back unchanged (DDF slots, and rho/u where those are written): memory sectors at
 	// obstacle surfaces are then written whole, which costs far less than the partial writes left by lanes that drop out.
 	// Waves made of skipped cells only, and the halo columns, leave at once.
-	const uint8_t flagsn = ld<uint8_t>(a.flags+row0, x), bo = flagsn&TYPE_BO;
+	const uint8_t flagsn = HAVE_FLAG ? (uint8_t)flag : ld<uint8_t>(a.flags+row0, x), bo = flagsn&TYPE_BO;
 	const bool halo_x = a.hx && (x == 0u || x == a.Nx-1u), skip = bo == TYPE_S || halo_x;
 	if (__ballot(!skip) == 0ull || halo_x) return;
 	auto feat = [&]() { if constexpr (FEAT >= 0) return StaticFeat<(uint32_t)(FEAT >= 0 ? FEAT : 0)>{}; else return DynamicFeat{a.features}; }();
@@ -73,12 +74,13 @@ __global__ __launch_bounds__(256) void k_collide(const Args a) {
 		pa[i+1] = fi+(uint64_t)sB*a.S+((uint64_t)zq[cz == 0 ? 0 : cz > 0 ? 1 : 2]*a.Ny+yq[cy == 0 ? 0 : cy > 0 ? 1 : 2])*a.Nx;
 	});
 	if (!FIELDS_ONLY || !skip) {
-		r[0] = ld<raw>(pa[0], xb);
+		if constexpr (MEM != MEM_LOAD_COHERENT) r[0] = ld_ddf<raw, MEM>(pa[0], xb);
 		static_for<1, Q, 2>([&](auto I) {
 			constexpr int i = I, cx = dir<Q>(i,0);
-			r[i] = ld<raw>(pa[i], xb);
-			r[i+1] = ld<raw>(pa[i+1], cx == 0 ? xb : cx > 0 ? xpb : xmb);
+			r[i] = ld_ddf<raw, MEM>(pa[i], xb);
+			r[i+1] = ld_ddf<raw, MEM>(pa[i+1], cx == 0 ? xb : cx > 0 ? xpb : xmb);
 		});
+		if constexpr (MEM == MEM_LOAD_COHERENT) r[0] = ld_ddf<raw, MEM>(pa[0], xb); // last: the compiler waits for this one at once (it keeps a second copy of the value)
 	}
 
 	// ---- boundaries, moments, collision
@@ -108,12 +110,94 @@ __global__ __launch_bounds__(256) void k_collide(const Args a) {
 
 	// ---- streaming part 1: scatter to the slots that were read (kernel.cpp:1339-1345)
 	const uint32_t sxb = fresh(xb), sxpb = fresh(xpb), sxmb = fresh(xmb);
-	st(pa[0], sxb, r[0]);
+	st_ddf<MEM>(pa[0], sxb, r[0]);
 	static_for<1, Q, 2>([&](auto I) {
 		constexpr int i = I, cx = dir<Q>(i,0);
-		st(pa[i], sxb, r[i]);
-		st(pa[i+1], cx == 0 ? sxb : cx > 0 ? sxpb : sxmb, r[i+1]);
+		st_ddf<MEM>(pa[i], sxb, r[i]);
+		st_ddf<MEM>(pa[i+1], cx == 0 ? sxb : cx > 0 ? sxpb : sxmb, r[i+1]);
 	});
+}
+template <int Q, int ST, int COLL, int FEAT, bool FIELDS_ONLY>
+__global__ __launch_bounds__(256) void k_collide(const Args a) {
+	// grid = (xchunks*Ny, planes): a launch may not exceed 2^32 work-items per grid dimension, and 1600^3 lattices do
+	collide_row<Q, ST, COLL, FEAT, FIELDS_ONLY>(a, blockIdx.x%a.xchunks, blockIdx.x/a.xchunks, a.z0+blockIdx.y);
+}
+
+// ---------------------------------------------------------------------------------------------- two time steps in one launch
+// k_collide_pair runs step t and step t+1 of a lattice that is periodic in z (no halo) in ONE launch, step t+1 trailing
+// step t by a few planes, so that step t+1 finds the DDFs step t wrote in the 256 MiB Infinity Cache instead of in HBM
+// (the reference launches one kernel per step, lbm.cpp:1411-1459; the result is the same bits, since every cell still
+// sees exactly the values the previous step left).
+//   Order of work (blockIdx.y = plane task, dispatched in ascending order): step t on planes 0..lag+1, then alternately
+//   step t+1 on plane p and step t on plane p+lag, at the end step t+1 on the planes next to the periodic seam
+//   (Nz-lag .. Nz-1, 0, 1).  A workgroup works on one row chunk of one step: with both steps' rows in one workgroup the
+//   second step's loads would queue behind the drain of the first step's stores (measured: 67 % of 8 TB/s against 78 %
+//   with nothing waiting at all).
+//   Dependence: a cell of step t+1 in plane p touches slots in planes p-1..p+1, whose step-t owners sit in planes p-2..p+2
+//   (esoteric-pull: a slot belongs to the cell at its place or to the cell one step against c_i, kernel.cpp:1332-1345).
+//   Every step-t workgroup counts itself done (a counter per plane and shard; the last arriver of a shard reports to the
+//   plane's word), every step-t+1 workgroup waits until the five planes p-2..p+2 have all their shards reported.  With
+//   lag >= 3 a workgroup only ever waits for workgroups with smaller grid indices, which have been dispatched before it.
+//   The wait is bounded: when it runs out the workgroup sets *error and goes on (the host then reports the failure).
+//   Visibility between workgroups of the launch (per-XCD L2s are not coherent, a CU's L1 is never refreshed): step t
+//   stores its DDFs written through at agent scope, drains them (s_waitcnt vmcnt(0) in every wave, then a workgroup
+//   barrier) before one lane counts the workgroup done with an agent-scope atomic; step t+1 polls with agent-scope loads,
+//   passes a workgroup barrier and loads its DDFs at agent scope.  Step t+1 stores plainly: the next launch reads that.
+//   Step t never reads a byte written in this launch (it runs ahead of step t+1 by more than the two planes step t+1
+//   writes beyond its own), so its loads are plain.
+// Not for UPDATE_FIELDS (both steps would write rho/u of a cell from different XCDs with no order between the write-backs).
+struct PairArgs {
+	uint32_t* plane_done; // PAIR_REPLICAS arrays, replica_stride words apart, of Nz words: shards of the plane that have reported (zeroed before the launch)
+	uint32_t replica_stride;
+	uint32_t* shard_done; // Nz*PAIR_SHARDS counters, 64 bytes apart (zeroed before the launch)
+	uint32_t* error;      // set to 1 by a wait that ran out
+	uint32_t lag;         // >= 3
+	uint32_t spin_limit;  // polls before a wait gives up
+};
+// The plane words are kept in PAIR_REPLICAS copies on cache lines of their own: every waiting workgroup of a plane asks
+// about the same five words, and a thousand workgroups asking one line queue up at its memory channel.
+constexpr uint32_t PAIR_SHARDS = 8u, PAIR_SHARD_STRIDE = 16u, PAIR_REPLICAS = 16u;
+template <int Q, int ST, int COLL, int FEAT>
+__global__ __launch_bounds__(256) void k_collide_pair(const Args a, const PairArgs p) {
+	const uint32_t Nz = a.Nz, lag = p.lag, task = blockIdx.y, per_plane = gridDim.x, in_plane = blockIdx.x;
+	const uint32_t ahead = lag+2u, paired = 2u*(Nz-lag-2u);
+	uint32_t z, second = 0u;
+	if (task < ahead) z = task;
+	else if (task < ahead+paired) { const uint32_t k = task-ahead; second = (k&1u)^1u; z = second ? 2u+k/2u : ahead+k/2u; }
+	else { second = 1u; z = Nz-lag+(task-ahead-paired); if (z >= Nz) z -= Nz; }
+	const uint32_t chunk = in_plane%a.xchunks, y = in_plane/a.xchunks;
+	if (!second) {
+		collide_row<Q, ST, COLL, FEAT, false, MEM_STORE_THROUGH>(a, chunk, y, z);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's stores have been acknowledged
+		__syncthreads();
+		if (threadIdx.x < 64u) {
+			const uint32_t shard = in_plane%PAIR_SHARDS, members = per_plane/PAIR_SHARDS+(shard < per_plane%PAIR_SHARDS ? 1u : 0u);
+			uint32_t before = 0u;
+			if (threadIdx.x == 0u) before = __hip_atomic_fetch_add(p.shard_done+((uint64_t)z*PAIR_SHARDS+shard)*PAIR_SHARD_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const bool last = __shfl((int)(before+1u == members), 0) != 0; // the shard's last arriver reports to every replica of the plane's word
+			if (last && threadIdx.x < PAIR_REPLICAS) __hip_atomic_fetch_add(p.plane_done+(uint64_t)threadIdx.x*p.replica_stride+z, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+	} else {
+		// the row's flags (never written by a step) are fetched while the question below is under way
+		const uint32_t x = chunk*blockDim.x+threadIdx.x;
+		uint32_t early = 0u;
+		if (x < a.Nx) early = ld<uint8_t>(a.flags+((uint64_t)z*a.Ny+y)*a.Nx, x);
+		if (threadIdx.x < 64u) {
+			const uint32_t lane = threadIdx.x, shards = per_plane < PAIR_SHARDS ? per_plane : PAIR_SHARDS; // shards without members never report
+			const uint32_t zz = (z+Nz-2u+(lane < 5u ? lane : 0u))%Nz;
+			for (uint32_t spins = 0u; ; spins++) {
+				bool ok = true;
+				if (lane < 5u) ok = __hip_atomic_load(p.plane_done+(uint64_t)(in_plane%PAIR_REPLICAS)*p.replica_stride+zz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= shards;
+				if (__ballot(!ok) == 0ull) break;
+				if (spins >= p.spin_limit) { if (lane == 0u) __hip_atomic_store(p.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+				if (spins < 2u) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(127); // a workgroup that is ahead of the first step asks rarely: its questions share the memory system with the work it waits for
+			}
+		}
+		__syncthreads();
+		Args b = a;
+		b.odd = a.odd^1u;
+		collide_row<Q, ST, COLL, FEAT, false, MEM_LOAD_COHERENT, true>(b, chunk, y, z, early);
+	}
 }
 
 // elements v, v+1 of a V-element raw vector as one pair (16-bit formats: one dword; FP32: two floats)

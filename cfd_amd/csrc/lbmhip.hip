@@ -51,6 +51,11 @@ struct lbmhip_domain {
 	void* mesh; uint64_t mesh_capacity; // triangle corners of the last voxelized mesh (grown on demand)
 	void* partial; // per-workgroup partial sums of the object_* reductions (kObjectSumBlocks float4)
 	float w;
+	// two time steps per launch (k_collide_pair): completion counters of the first step's workgroups, then one error word
+	uint32_t* pair_sync; uint64_t pair_sync_words; uint32_t pair_replica_stride;
+	int fuse, pair_lag, pair_blocks_per_cu; // fuse: -1 = automatic, 0 = never, 1 = whenever a compiled instance exists; pair_lag 0 = automatic; pair_blocks_per_cu -1 = automatic
+	int pair_used, pair_used_lag, pair_used_blocks_per_cu, pair_unchecked; // what the last lbmhip_stream_collide_steps call ran; launches since the error word was last read
+	int compute_units;
 };
 
 // 64-bit safe fill (fields of the largest lattices exceed what 32-bit element counts can address)
@@ -268,6 +273,15 @@ int lbmhip_domain_create(const lbmhip_config* c, lbmhip_domain** out) {
 		}
 	}
 	e = hipMalloc(&d->partial, kObjectSumBlocks*4u*sizeof(float));
+	d->fuse = -1; d->pair_lag = 0; d->pair_blocks_per_cu = -1;
+	{ const char* env = getenv("LBMHIP_FUSE"); if (env && (env[0] == '0' || env[0] == '1') && !env[1]) d->fuse = env[0]-'0'; }
+	if (e == hipSuccess) e = hipDeviceGetAttribute(&d->compute_units, hipDeviceAttributeMultiprocessorCount, c->device);
+	if (e == hipSuccess && c->Dx*c->Dy*c->Dz == 1u && c->Nz >= 8u) { // what k_collide_pair needs, whether or not it is ever used (264 KB at 512 planes)
+		d->pair_replica_stride = (c->Nz+63u)/64u*64u+32u; // the replicas start on different cache lines, an odd number of lines apart
+		d->pair_sync_words = (uint64_t)PAIR_REPLICAS*d->pair_replica_stride+(uint64_t)c->Nz*PAIR_SHARDS*PAIR_SHARD_STRIDE+16u;
+		e = hipMalloc((void**)&d->pair_sync, d->pair_sync_words*sizeof(uint32_t));
+		if (e == hipSuccess) e = hipMemsetAsync(d->pair_sync, 0, d->pair_sync_words*sizeof(uint32_t), d->stream);
+	}
 	if (e == hipSuccess) e = hipEventCreate(&d->ev_start);
 	if (e == hipSuccess) e = hipEventCreate(&d->ev_stop);
 	if (e == hipSuccess) e = hipEventCreate(&d->ev_tune0);
@@ -290,6 +304,7 @@ int lbmhip_domain_destroy(lbmhip_domain* d) {
 	for (int k = 0; k < 5; k++) if (d->field[k]) (void)hipFree(d->field[k]);
 	for (int k = 0; k < 4; k++) if (d->halo_own[k]) (void)hipFree(d->halo_own[k]);
 	if (d->partial) (void)hipFree(d->partial);
+	if (d->pair_sync) (void)hipFree(d->pair_sync);
 	if (d->mesh) (void)hipFree(d->mesh);
 	if (d->ev_start) (void)hipEventDestroy(d->ev_start);
 	if (d->ev_stop) (void)hipEventDestroy(d->ev_stop);
@@ -320,13 +335,27 @@ int lbmhip_get_stream(lbmhip_domain* d, void** stream) {
 	*stream = (void*)d->stream;
 	return 0;
 }
+// After the stream has been synchronised: did a wait inside a two-step launch run out?  (It cannot while workgroups are
+// dispatched in grid order; if it ever does, the lattice holds wrong values and the caller must know.)
+static int pair_check(lbmhip_domain* d) {
+	if (!d->pair_unchecked || !d->pair_sync) return 0;
+	uint32_t flag = 0u;
+	HIP_TRY(hipMemcpy(&flag, d->pair_sync+d->pair_sync_words-16u, sizeof(flag), hipMemcpyDeviceToHost));
+	d->pair_unchecked = 0;
+	if (flag) {
+		(void)hipMemset(d->pair_sync+d->pair_sync_words-16u, 0, sizeof(flag));
+		d->fuse = 0;
+		return fail("a two-step launch gave up waiting for its first step: the lattice is invalid (two-step launches are now off for this domain; LBMHIP_FUSE=0 avoids them)");
+	}
+	return 0;
+}
 int lbmhip_sync(lbmhip_domain* d) {
 	NEED(d, "null domain");
 	DeviceGuard g(d->cfg.device);
 	HIP_TRY(hipStreamSynchronize(d->stream));
 	if (d->saved_stream) HIP_TRY(hipStreamSynchronize(d->saved_stream));
 	if (d->comm_stream != d->stream) HIP_TRY(hipStreamSynchronize(d->comm_stream));
-	return 0;
+	return pair_check(d);
 }
 int lbmhip_comm_begin(lbmhip_domain* d) {
 	NEED(d, "null domain");
@@ -389,7 +418,7 @@ int lbmhip_download(lbmhip_domain* d, int field, void* host, uint64_t offset, ui
 	if (field == LBMHIP_FIELD_FI && d->stride != d->N) HIP_TRY(copy_ddfs(d, host, offset, bytes, false));
 	else HIP_TRY(hipMemcpyAsync(host, (const char*)d->field[field]+offset, bytes, hipMemcpyDeviceToHost, d->stream));
 	HIP_TRY(hipStreamSynchronize(d->stream));
-	return 0;
+	return pair_check(d);
 }
 int lbmhip_field_pointer(lbmhip_domain* d, int field, void** p, uint64_t* bytes) {
 	NEED(d && p, "null argument");
@@ -411,6 +440,9 @@ int lbmhip_set_tuning(lbmhip_domain* d, const char* key, int value) {
 	if (!strcmp(key, "blocks_per_cu")) { NEED(value >= -1 && value <= 32, "blocks_per_cu must be -1 (auto), 0 (no limit) or 1..32"); d->blocks_per_cu = value; return 0; }
 	if (!strcmp(key, "block")) { NEED(value == 0 || (value >= 64 && value <= 256 && value%64 == 0), "block must be 0 (auto), 64, 128, 192 or 256"); d->block = value; return 0; }
 	if (!strcmp(key, "autotune")) { NEED(value == 0 || value == 1, "autotune must be 0 or 1"); d->autotune = value; if (!value) { d->tuned = 0; d->tune_launches = 0; d->tune_pending = -1; } return 0; }
+	if (!strcmp(key, "fuse")) { NEED(value >= -1 && value <= 1, "fuse must be -1 (auto), 0 or 1"); d->fuse = value; return 0; }
+	if (!strcmp(key, "pair_lag")) { NEED(value == 0 || (value >= 3 && value <= 64), "pair_lag must be 0 (auto) or 3..64"); d->pair_lag = value; return 0; }
+	if (!strcmp(key, "pair_blocks_per_cu")) { NEED(value >= -1 && value <= 32, "pair_blocks_per_cu must be -1 (auto), 0 (no limit) or 1..32"); d->pair_blocks_per_cu = value; return 0; }
 	return fail("unknown tuning key '%s'", key);
 }
 int lbmhip_get_tuning(lbmhip_domain* d, const char* key, int* value) {
@@ -422,6 +454,10 @@ int lbmhip_get_tuning(lbmhip_domain* d, const char* key, int* value) {
 	if (!strcmp(key, "autotune")) { *value = d->autotune; return 0; }
 	if (!strcmp(key, "tuned")) { *value = d->tuned; return 0; }
 	if (!strcmp(key, "jit")) { *value = d->uses_jit; return 0; }
+	if (!strcmp(key, "fuse")) { *value = d->fuse; return 0; }
+	if (!strcmp(key, "fused")) { *value = d->pair_used; return 0; } // the last lbmhip_stream_collide_steps call ran two steps per launch
+	if (!strcmp(key, "pair_lag")) { *value = d->pair_used ? d->pair_used_lag : d->pair_lag; return 0; }
+	if (!strcmp(key, "pair_blocks_per_cu")) { *value = d->pair_used ? d->pair_used_blocks_per_cu : d->pair_blocks_per_cu; return 0; }
 	return fail("unknown tuning key '%s'", key);
 }
 
@@ -630,6 +666,61 @@ int lbmhip_initialize(lbmhip_domain* d) {
 int lbmhip_stream_collide(lbmhip_domain* d, uint64_t t, float fx, float fy, float fz) {
 	NEED(d, "null domain");
 	return launch_collide_planes(d, t, fx, fy, fz, 0u, d->cfg.Nz, false);
+}
+// Two steps per launch: when does it apply, and with which geometry?  The lattice must be one periodic domain (a step
+// between two exchanges cannot be paired), without UPDATE_FIELDS, with a compiled k_collide_pair instance; and the planes
+// that lie between the two steps (lag + 4 of them) must fit the Infinity Cache with room to spare, else the second step
+// reads from HBM like a launch of its own and only the waiting is left.  lag = 3 + the whole planes the resident
+// workgroups cover: the second step then asks for planes whose workgroups have left, and its question costs one memory
+// round trip instead of a wait.  Measured at 512^3 D3Q19 FP32 (20 MB planes, tools/fused_sweep.py): at most 6 workgroups
+// per CU and lag 4 (72.5 % of 8 TB/s against 68.4 % with a launch per step; lag 3: 62 %, lag 6: 69 %; no cap, lag 5: 70 %).
+// Automatic mode (fuse = -1) pairs only where it was measured to pay: plain D3Q19 SRT with FP32 DDFs and planes of at
+// least 1024 workgroups (512^3: 38 100 against 35 900 MLUPs/s; 384^3 and 256^3 lose 5-8 %, their planes are a fraction of
+// what is resident; the TRT + subgrid channel kernel, 3 workgroups per CU, loses 5 %).  fuse = 1 pairs whenever it can.
+static const uint64_t kPairWindowBytes = 200ull<<20;
+static bool pair_plan(const lbmhip_domain* d, pair_launch_fn* fn, uint32_t* lag, int* blocks_per_cu, uint32_t* xchunks, uint32_t* block) {
+	if (d->fuse == 0 || !d->pair_sync || (d->cfg.features&LBMHIP_UPDATE_FIELDS)) return false;
+	*fn = select_collide_pair((int)d->cfg.velocity_set, (int)d->cfg.storage, (int)d->cfg.collision, (int)d->cfg.features);
+	if (!*fn) return false;
+	*block = std::min(256u, (d->cfg.Nx+63u)/64u*64u);
+	*xchunks = (d->cfg.Nx+*block-1u)/(*block);
+	const uint64_t per_plane = (uint64_t)*xchunks*d->cfg.Ny;
+	if (per_plane*(*block) >= 0xFFFFFFFFull || 2u*d->cfg.Nz > 65535u) return false;
+	*blocks_per_cu = d->pair_blocks_per_cu >= 0 ? d->pair_blocks_per_cu : 6;
+	const uint64_t resident = (uint64_t)d->compute_units*(uint64_t)(*blocks_per_cu > 0 ? std::min(*blocks_per_cu*256/(int)*block, 8*256/(int)*block) : 8*256/(int)*block);
+	*lag = d->pair_lag ? (uint32_t)d->pair_lag : 3u+(uint32_t)(resident/per_plane);
+	if (d->cfg.Nz < *lag+4u) return false;
+	const uint64_t plane_bytes = (uint64_t)d->cfg.Nx*d->cfg.Ny*d->cfg.velocity_set*d->fpxx_bytes;
+	if (d->fuse < 0 && ((uint64_t)(*lag+4u)*plane_bytes > kPairWindowBytes || per_plane < 1024u || d->cfg.velocity_set != 19u || d->cfg.storage != LBMHIP_FP32 ||
+	                    d->cfg.collision != LBMHIP_SRT || d->cfg.features != 0u)) return false;
+	return true;
+}
+static int launch_collide_pair_steps(lbmhip_domain* d, pair_launch_fn fn, uint64_t t, float fx, float fy, float fz, uint32_t lag, int blocks_per_cu, uint32_t xchunks, uint32_t block) {
+	DeviceGuard g(d->cfg.device);
+	Args a = make_args(d, t, fx, fy, fz);
+	a.xchunks = xchunks; a.z0 = 0u; a.z1 = d->cfg.Nz;
+	PairArgs p;
+	p.plane_done = d->pair_sync; p.replica_stride = d->pair_replica_stride; p.shard_done = d->pair_sync+(uint64_t)PAIR_REPLICAS*d->pair_replica_stride; p.error = d->pair_sync+d->pair_sync_words-16u;
+	p.lag = lag; p.spin_limit = 500000u; // about two seconds of polling (3.4 us of sleep between two polls)
+	HIP_TRY(hipMemsetAsync(d->pair_sync, 0, (d->pair_sync_words-16u)*sizeof(uint32_t), d->stream));
+	if (blocks_per_cu > 0) blocks_per_cu = std::max(1, blocks_per_cu*256/(int)block);
+	const uint32_t lds = blocks_per_cu > 0 ? ((160u*1024u/(uint32_t)blocks_per_cu)&~255u) : 0u;
+	HIP_TRY(fn(a, p, dim3(xchunks*d->cfg.Ny, 2u*d->cfg.Nz), dim3(block), lds, d->stream));
+	d->pair_unchecked = 1;
+	return 0;
+}
+int lbmhip_stream_collide_steps(lbmhip_domain* d, uint64_t t, uint32_t steps, float fx, float fy, float fz) {
+	NEED(d, "null domain");
+	pair_launch_fn fn = nullptr;
+	uint32_t lag = 0u, xchunks = 1u, block = 256u, done = 0u;
+	int blocks_per_cu = 0;
+	d->pair_used = 0;
+	if (steps >= 2u && pair_plan(d, &fn, &lag, &blocks_per_cu, &xchunks, &block)) {
+		for (; steps-done >= 2u; done += 2u) { const int status = launch_collide_pair_steps(d, fn, t+done, fx, fy, fz, lag, blocks_per_cu, xchunks, block); if (status) return status; }
+		d->pair_used = 1; d->pair_used_lag = (int)lag; d->pair_used_blocks_per_cu = blocks_per_cu;
+	}
+	for (; done < steps; done++) { const int status = launch_collide_planes(d, t+done, fx, fy, fz, 0u, d->cfg.Nz, false); if (status) return status; }
+	return 0;
 }
 int lbmhip_stream_collide_planes(lbmhip_domain* d, uint64_t t, float fx, float fy, float fz, uint32_t z_begin, uint32_t z_end) {
 	NEED(d, "null domain");
@@ -1010,7 +1101,7 @@ int lbmhip_timer_stop(lbmhip_domain* d, float* ms) {
 	HIP_TRY(hipEventRecord(d->ev_stop, d->stream));
 	HIP_TRY(hipEventSynchronize(d->ev_stop));
 	HIP_TRY(hipEventElapsedTime(ms, d->ev_start, d->ev_stop));
-	return 0;
+	return pair_check(d);
 }
 
 } // extern "C"

@@ -40,6 +40,9 @@ class SlabOps:
     def download(self, names): raise NotImplementedError
     def initialize(self): raise NotImplementedError
     def collide_planes(self, t, f, z0, z1): raise NotImplementedError
+    def collide_steps(self, t, f, steps):  # `steps` whole-lattice steps with nothing in between (a single rank only)
+        for k in range(steps):
+            self.collide_planes(t + k, f, 0, self.local[2])
     def update_fields(self, t, f): raise NotImplementedError
     def update_force_field(self, t): raise NotImplementedError
     def pack(self, what, t): raise NotImplementedError
@@ -114,6 +117,9 @@ class HipSlabOps(SlabOps):
 
     def collide_planes(self, t, f, z0, z1):
         L.check(self.lib.lbmhip_stream_collide_planes(self.dom.h, C.c_uint64(t), C.c_float(f[0]), C.c_float(f[1]), C.c_float(f[2]), int(z0), int(z1)))
+
+    def collide_steps(self, t, f, steps):
+        L.check(self.lib.lbmhip_stream_collide_steps(self.dom.h, C.c_uint64(t), C.c_uint32(steps), C.c_float(f[0]), C.c_float(f[1]), C.c_float(f[2])))
 
     def update_fields(self, t, f):
         L.check(self.lib.lbmhip_update_fields(self.dom.h, C.c_uint64(t), C.c_float(f[0]), C.c_float(f[1]), C.c_float(f[2])))
@@ -308,8 +314,14 @@ class DistributedLBM:
         with self.ops.scope():
             if not self.initialized:
                 self._initialize()
-            for _ in range(int(steps)):
-                self._do_time_step()
+            if self.world <= 1 and int(steps) > 0:  # no exchange between the steps: the engine may pair them (lbmhip_stream_collide_steps)
+                self.ops.collide_steps(self.t, self.f, int(steps))
+                self.t += int(steps)
+                if self.update_fields_ext:
+                    self.t_last_update_fields = self.t
+            else:
+                for _ in range(int(steps)):
+                    self._do_time_step()
         self.ops.sync()
 
     def update_fields(self):

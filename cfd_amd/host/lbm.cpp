@@ -135,6 +135,7 @@ LBM_Domain::~LBM_Domain() { lbmhip_domain_destroy(handle); }
 uint LBM_Domain::get_velocity_set() const { return velocity_set; }
 void LBM_Domain::enqueue_initialize() { check(lbmhip_initialize(handle)); }
 void LBM_Domain::enqueue_stream_collide() { check(lbmhip_stream_collide(handle, t, fx, fy, fz)); }
+void LBM_Domain::enqueue_stream_collide_steps(const uint steps) { check(lbmhip_stream_collide_steps(handle, t, steps, fx, fy, fz)); }
 void LBM_Domain::enqueue_stream_collide_planes(const uint z0, const uint z1) { check(lbmhip_stream_collide_planes(handle, t, fx, fy, fz, z0, z1)); }
 void LBM_Domain::enqueue_update_fields() { // lbm.cpp:238-246
 	if (lbm_features()&LBMHIP_UPDATE_FIELDS) return;
@@ -348,7 +349,10 @@ void LBM::run(const ulong steps, const ulong total_steps) { // lbm.cpp:1461-1489
 		if (!running) break;
 		const ulong n = std::min(batch, steps-i);
 		clock.start();
-		for (ulong k = 0ull; k < n; k++) do_time_step();
+		if (get_D() == 1u) { // no exchange between the steps: the library may run them two per launch (lbmhip_stream_collide_steps)
+			lbm_domain[0]->enqueue_stream_collide_steps((uint)n);
+			lbm_domain[0]->increment_time_step((uint)n);
+		} else for (ulong k = 0ull; k < n; k++) do_time_step();
 		for (LBM_Domain* d : lbm_domain) d->finish_queue();
 		const double dt = clock.stop()/(double)n;
 		for (ulong k = 0ull; k < n; k++) info.update(dt);

@@ -77,6 +77,7 @@ public:
 	void enqueue_initialize();
 	void enqueue_stream_collide();
 	void enqueue_stream_collide_planes(const uint z0, const uint z1);
+	void enqueue_stream_collide_steps(const uint steps); // `steps` steps with nothing in between (single-domain lattices)
 	void enqueue_update_fields();
 	void enqueue_update_force_field();
 	void enqueue_update_moving_boundaries();

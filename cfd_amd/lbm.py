@@ -380,8 +380,14 @@ class LBM:
     def run(self, steps):
         if not self.initialized:
             self.initialize()
-        for _ in range(int(steps)):
-            self.do_time_step()
+        if len(self.domains) == 1 and int(steps) > 0:  # no exchange between the steps: the library may run them two per launch
+            check(self._L.lbmhip_stream_collide_steps(self.domains[0].h, C.c_uint64(self.t), C.c_uint32(int(steps)), C.c_float(self.fx), C.c_float(self.fy), C.c_float(self.fz)))
+            self.t += int(steps)
+            if self.update_fields_ext:
+                self.t_last_update_fields = self.t
+        else:
+            for _ in range(int(steps)):
+                self.do_time_step()
         self.sync()
 
     # ---- LBM::update_fields / enqueue_update_fields (lbm.cpp:238-246, 1491-1496)

@@ -117,6 +117,15 @@ int lbmhip_stream_collide(lbmhip_domain* domain, uint64_t t, float fx, float fy,
 /* the same step restricted to lattice planes z in [z_begin, z_end) (local coordinates); lets a caller run the
  * planes next to a halo first and overlap their exchange with the rest.  Cells are independent within a step. */
 int lbmhip_stream_collide_planes(lbmhip_domain* domain, uint64_t t, float fx, float fy, float fz, uint32_t z_begin, uint32_t z_end);
+/* `steps` consecutive steps t, t+1, ... with one force, nothing else happening in between: what LBM::run does per domain
+ * when no exchange, force-field update or export falls between the steps (lbm.cpp:1354-1459, one stream_collide launch
+ * per step there).  A single periodic domain without UPDATE_FIELDS runs them two per launch, the second step trailing
+ * the first by a few lattice planes so that it reads the first step's DDFs from the Infinity Cache (same bits as
+ * `steps` calls of lbmhip_stream_collide; lattices whose planes are too large for that, and every other
+ * configuration, run one launch per step).  Tuning keys: "fuse" (-1 automatic, 0 never, 1 whenever possible),
+ * "pair_lag", "pair_blocks_per_cu"; "fused" reads back whether the last call paired its steps.  Environment:
+ * LBMHIP_FUSE=0|1. */
+int lbmhip_stream_collide_steps(lbmhip_domain* domain, uint64_t t, uint32_t steps, float fx, float fy, float fz);
 int lbmhip_update_fields(lbmhip_domain* domain, uint64_t t, float fx, float fy, float fz); /* kernel.cpp:1812-1894 */
 int lbmhip_update_force_field(lbmhip_domain* domain, uint64_t t);                          /* kernel.cpp:1897-1910 */
 int lbmhip_reset_force_field(lbmhip_domain* domain);                                       /* kernel.cpp:1911-1917 */

@@ -1,0 +1,97 @@
+"""GPU: lbmhip_stream_collide_steps (two time steps per launch on a single periodic domain) gives the bits of stepwise
+lbmhip_stream_collide calls and of the CPU oracle.
+
+The second step of a launch only waits for workgroups of the first; a short lag makes those waits real (workgroups of the
+planes asked for are still running), a long one makes them trivial - both must give the same lattice.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import cfd_amd
+from cfd_amd import setups
+from oracle import harness as H
+
+pytestmark = pytest.mark.gpu
+
+TGV = dict(N=(96, 64, 48), nu=0.02)
+CHANNEL = dict(N=(320, 64, 40), nu=0.01, features=("VOLUME_FORCE", "SUBGRID"), f=(2e-4, 0.0, 0.0), collision="TRT")
+Q27 = dict(N=(64, 48, 40), nu=0.03, Q=27)
+
+
+def fused_flag(lbm):
+    v = C.c_int(-1)
+    cfd_amd.lbm.check(cfd_amd.lib().lbmhip_get_tuning(lbm.domains[0].h, b"fused", C.byref(v)))
+    return v.value
+
+
+def bits(a):
+    return a.view(np.uint32 if a.dtype == np.float32 else np.uint16)
+
+
+@pytest.mark.parametrize("lag,cap", [(3, 0), (5, 0), (4, 3), (9, 2)])
+@pytest.mark.parametrize("kw,setup,steps", [(TGV, setups.taylor_green, 7), (CHANNEL, setups.channel, 10), (Q27, setups.taylor_green, 4)])
+def test_paired_steps_equal_single_steps(gpu, kw, setup, steps, lag, cap):
+    a = cfd_amd.LBM(**kw); b = cfd_amd.LBM(**kw)
+    try:
+        for lbm, fuse in ((a, 1), (b, 0)):
+            lbm.set_tuning("fuse", fuse)
+            setup(lbm)
+        a.set_tuning("pair_lag", lag); a.set_tuning("pair_blocks_per_cu", cap)
+        a.run(steps); b.run(steps)
+        assert fused_flag(a) == 1 and fused_flag(b) == 0
+        assert np.array_equal(bits(a.domains[0].download_fi()), bits(b.domains[0].download_fi())), "DDFs differ"
+        a.read_from_device(); b.read_from_device()
+        assert np.array_equal(bits(a.rho), bits(b.rho)) and np.array_equal(bits(a.u), bits(b.u))
+        a.run(1); b.run(1)  # a single step after paired ones
+        assert fused_flag(a) == 0
+        assert np.array_equal(bits(a.domains[0].download_fi()), bits(b.domains[0].download_fi())), "DDFs differ after the odd step"
+    finally:
+        a.close(); b.close()
+
+
+def test_paired_steps_equal_the_oracle(gpu):
+    a = cfd_amd.LBM(**CHANNEL); b = H.OracleLBM(**CHANNEL)
+    try:
+        a.set_tuning("fuse", 1); a.set_tuning("pair_lag", 3)
+        setups.channel(a); setups.channel(b)
+        a.run(12); b.run(12)
+        assert fused_flag(a) == 1
+        assert np.array_equal(bits(a.domains[0].download_fi()), bits(b.domains[0].fi)), "DDFs differ from the oracle"
+        a.read_from_device(); b.read_from_device()
+        assert np.array_equal(a.flags, b.flags)
+        assert np.array_equal(bits(a.rho), bits(b.rho)) and np.array_equal(bits(a.u), bits(b.u))
+    finally:
+        a.close()
+
+
+def test_what_is_never_paired(gpu):
+    """UPDATE_FIELDS, several domains, lattices with too few planes and feature sets without an instance run one launch per step."""
+    for kw in (dict(N=(64, 64, 48), nu=0.02, features=("UPDATE_FIELDS",)), dict(N=(64, 64, 48), nu=0.02, D=(1, 1, 2)), dict(N=(64, 64, 6), nu=0.02),
+               dict(N=(64, 64, 48), nu=0.02, features=("MOVING_BOUNDARIES",)), dict(N=(64, 64, 48), nu=0.02, storage="FP16S")):
+        a = cfd_amd.LBM(**kw); b = H.OracleLBM(**kw)
+        try:
+            a.set_tuning("fuse", 1)
+            setups.taylor_green(a); setups.taylor_green(b)
+            a.run(4); b.run(4)
+            assert fused_flag(a) == 0, kw
+            for da, db in zip(a.domains, b.domains):
+                assert np.array_equal(bits(da.download_fi()), bits(db.fi)), kw
+        finally:
+            a.close()
+
+
+def test_large_planes_pair_only_on_request(gpu):
+    """Automatic mode leaves lattices alone whose planes between the two steps would not fit the cache."""
+    kw = dict(N=(2048, 1024, 16), nu=0.02)
+    a = cfd_amd.LBM(**kw)
+    try:
+        setups.taylor_green(a)
+        a.run(2)
+        assert fused_flag(a) == 0
+        a.set_tuning("fuse", 1)
+        a.run(2)
+        assert fused_flag(a) == 1
+    finally:
+        a.close()
