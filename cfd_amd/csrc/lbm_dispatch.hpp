@@ -27,12 +27,12 @@ hipError_t launch_fields_wide(const Args& a, dim3 grid, dim3 block, uint32_t lds
 
 // two time steps in one launch (k_collide_pair); nullptr when the configuration has no compiled instance
 typedef hipError_t (*pair_launch_fn)(const Args&, const PairArgs&, dim3 grid, dim3 block, uint32_t lds_bytes, hipStream_t stream);
-template <int Q, int ST, int COLL, int FEAT>
+template <int Q, int ST, int COLL, int FEAT, int V, int P>
 hipError_t launch_collide_pair(const Args& a, const PairArgs& p, dim3 grid, dim3 block, uint32_t lds_bytes, hipStream_t stream) {
-	hipLaunchKernelGGL((k_collide_pair<Q, ST, COLL, FEAT>), grid, block, lds_bytes, stream, a, p);
+	hipLaunchKernelGGL((k_collide_pair<Q, ST, COLL, FEAT, V, P>), grid, block, lds_bytes, stream, a, p);
 	return hipGetLastError();
 }
-pair_launch_fn select_collide_pair(int Q, int ST, int COLL, int FEAT);
+pair_launch_fn select_collide_pair(int Q, int ST, int COLL, int FEAT, int V, int P); // V = 1 (FP32 DDFs) or 2 (16-bit DDFs)
 
 // FEAT < 0 selects the instance that reads the feature mask at run time; FO = update_fields (always run-time features)
 // V = cells per lane; P = 2 selects the instance that collides two cells at a time in packed arithmetic (V = 2 or 4 only)

@@ -123,83 +123,6 @@ __global__ __launch_bounds__(256) void k_collide(const Args a) {
 	collide_row<Q, ST, COLL, FEAT, FIELDS_ONLY>(a, blockIdx.x%a.xchunks, blockIdx.x/a.xchunks, a.z0+blockIdx.y);
 }
 
-// ---------------------------------------------------------------------------------------------- two time steps in one launch
-// k_collide_pair runs step t and step t+1 of a lattice that is periodic in z (no halo) in ONE launch, step t+1 trailing
-// step t by a few planes, so that step t+1 finds the DDFs step t wrote in the 256 MiB Infinity Cache instead of in HBM
-// (the reference launches one kernel per step, lbm.cpp:1411-1459; the result is the same bits, since every cell still
-// sees exactly the values the previous step left).
-//   Order of work (blockIdx.y = plane task, dispatched in ascending order): step t on planes 0..lag+1, then alternately
-//   step t+1 on plane p and step t on plane p+lag, at the end step t+1 on the planes next to the periodic seam
-//   (Nz-lag .. Nz-1, 0, 1).  A workgroup works on one row chunk of one step: with both steps' rows in one workgroup the
-//   second step's loads would queue behind the drain of the first step's stores (measured: 67 % of 8 TB/s against 78 %
-//   with nothing waiting at all).
-//   Dependence: a cell of step t+1 in plane p touches slots in planes p-1..p+1, whose step-t owners sit in planes p-2..p+2
-//   (esoteric-pull: a slot belongs to the cell at its place or to the cell one step against c_i, kernel.cpp:1332-1345).
-//   Every step-t workgroup counts itself done (a counter per plane and shard; the last arriver of a shard reports to the
-//   plane's word), every step-t+1 workgroup waits until the five planes p-2..p+2 have all their shards reported.  With
-//   lag >= 3 a workgroup only ever waits for workgroups with smaller grid indices, which have been dispatched before it.
-//   The wait is bounded: when it runs out the workgroup sets *error and goes on (the host then reports the failure).
-//   Visibility between workgroups of the launch (per-XCD L2s are not coherent, a CU's L1 is never refreshed): step t
-//   stores its DDFs written through at agent scope, drains them (s_waitcnt vmcnt(0) in every wave, then a workgroup
-//   barrier) before one lane counts the workgroup done with an agent-scope atomic; step t+1 polls with agent-scope loads,
-//   passes a workgroup barrier and loads its DDFs at agent scope.  Step t+1 stores plainly: the next launch reads that.
-//   Step t never reads a byte written in this launch (it runs ahead of step t+1 by more than the two planes step t+1
-//   writes beyond its own), so its loads are plain.
-// Not for UPDATE_FIELDS (both steps would write rho/u of a cell from different XCDs with no order between the write-backs).
-struct PairArgs {
-	uint32_t* plane_done; // PAIR_REPLICAS arrays, replica_stride words apart, of Nz words: shards of the plane that have reported (zeroed before the launch)
-	uint32_t replica_stride;
-	uint32_t* shard_done; // Nz*PAIR_SHARDS counters, 64 bytes apart (zeroed before the launch)
-	uint32_t* error;      // set to 1 by a wait that ran out
-	uint32_t lag;         // >= 3
-	uint32_t spin_limit;  // polls before a wait gives up
-};
-// The plane words are kept in PAIR_REPLICAS copies on cache lines of their own: every waiting workgroup of a plane asks
-// about the same five words, and a thousand workgroups asking one line queue up at its memory channel.
-constexpr uint32_t PAIR_SHARDS = 8u, PAIR_SHARD_STRIDE = 16u, PAIR_REPLICAS = 16u;
-template <int Q, int ST, int COLL, int FEAT>
-__global__ __launch_bounds__(256) void k_collide_pair(const Args a, const PairArgs p) {
-	const uint32_t Nz = a.Nz, lag = p.lag, task = blockIdx.y, per_plane = gridDim.x, in_plane = blockIdx.x;
-	const uint32_t ahead = lag+2u, paired = 2u*(Nz-lag-2u);
-	uint32_t z, second = 0u;
-	if (task < ahead) z = task;
-	else if (task < ahead+paired) { const uint32_t k = task-ahead; second = (k&1u)^1u; z = second ? 2u+k/2u : ahead+k/2u; }
-	else { second = 1u; z = Nz-lag+(task-ahead-paired); if (z >= Nz) z -= Nz; }
-	const uint32_t chunk = in_plane%a.xchunks, y = in_plane/a.xchunks;
-	if (!second) {
-		collide_row<Q, ST, COLL, FEAT, false, MEM_STORE_THROUGH>(a, chunk, y, z);
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's stores have been acknowledged
-		__syncthreads();
-		if (threadIdx.x < 64u) {
-			const uint32_t shard = in_plane%PAIR_SHARDS, members = per_plane/PAIR_SHARDS+(shard < per_plane%PAIR_SHARDS ? 1u : 0u);
-			uint32_t before = 0u;
-			if (threadIdx.x == 0u) before = __hip_atomic_fetch_add(p.shard_done+((uint64_t)z*PAIR_SHARDS+shard)*PAIR_SHARD_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			const bool last = __shfl((int)(before+1u == members), 0) != 0; // the shard's last arriver reports to every replica of the plane's word
-			if (last && threadIdx.x < PAIR_REPLICAS) __hip_atomic_fetch_add(p.plane_done+(uint64_t)threadIdx.x*p.replica_stride+z, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		}
-	} else {
-		// the row's flags (never written by a step) are fetched while the question below is under way
-		const uint32_t x = chunk*blockDim.x+threadIdx.x;
-		uint32_t early = 0u;
-		if (x < a.Nx) early = ld<uint8_t>(a.flags+((uint64_t)z*a.Ny+y)*a.Nx, x);
-		if (threadIdx.x < 64u) {
-			const uint32_t lane = threadIdx.x, shards = per_plane < PAIR_SHARDS ? per_plane : PAIR_SHARDS; // shards without members never report
-			const uint32_t zz = (z+Nz-2u+(lane < 5u ? lane : 0u))%Nz;
-			for (uint32_t spins = 0u; ; spins++) {
-				bool ok = true;
-				if (lane < 5u) ok = __hip_atomic_load(p.plane_done+(uint64_t)(in_plane%PAIR_REPLICAS)*p.replica_stride+zz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= shards;
-				if (__ballot(!ok) == 0ull) break;
-				if (spins >= p.spin_limit) { if (lane == 0u) __hip_atomic_store(p.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-				if (spins < 2u) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(127); // a workgroup that is ahead of the first step asks rarely: its questions share the memory system with the work it waits for
-			}
-		}
-		__syncthreads();
-		Args b = a;
-		b.odd = a.odd^1u;
-		collide_row<Q, ST, COLL, FEAT, false, MEM_LOAD_COHERENT, true>(b, chunk, y, z, early);
-	}
-}
-
 // elements v, v+1 of a V-element raw vector as one pair (16-bit formats: one dword; FP32: two floats)
 template <class raw2, int V, class rvec> __device__ __forceinline__ raw2 pair_of(const rvec& d, const int v) {
 	if constexpr (sizeof(raw2) == 4) { // 16-bit elements
@@ -227,8 +150,10 @@ template <class raw2, int V, class rvec> __device__ __forceinline__ void set_pai
 // P = 1: the V cells are collided one after the other; P = 2: two at a time in packed FP32 arithmetic (half the vector
 // arithmetic instructions, twice the live registers) - same bits either way.
 // FO = true is update_fields (kernel.cpp:1812-1894) with the same loads: moments only, rho/u written as whole vectors, no DDF stores (P = 1).
-template <int Q, int ST, int COLL, int FEAT, int V, int P, bool FO = false>
-__global__ __launch_bounds__(256, (P == 2 && V == 2 ? 3 : 1)) void k_collide_wide(const Args a) { // two cells in packed arithmetic: at least 3 waves per SIMD (at most 168 registers; 4 cells per lane would spill)
+// collide_row_wide is the work of one workgroup (x-chunk `chunk` of lattice row (y, z)); MEM as for collide_row (the
+// agent-scope forms move at most 4 bytes: two cells of 16-bit DDFs per lane).
+template <int Q, int ST, int COLL, int FEAT, int V, int P, bool FO = false, int MEM = MEM_PLAIN>
+__device__ __forceinline__ void collide_row_wide(const Args& a, const uint32_t chunk, const uint32_t y, const uint32_t z) {
 	using S = Store<ST>;
 	using raw = typename S::raw;
 	static_assert(V == 2 || V == 4, "vectors of 2 or 4 cells");
@@ -237,7 +162,6 @@ __global__ __launch_bounds__(256, (P == 2 && V == 2 ? 3 : 1)) void k_collide_wid
 	typedef raw rvec __attribute__((ext_vector_type(V)));
 	typedef uint8_t fvec __attribute__((ext_vector_type(V)));
 	typedef typename std::conditional<sizeof(raw) == 2, uint32_t, raw>::type lane_t; // what travels through a wave shuffle
-	const uint32_t chunk = blockIdx.x%a.xchunks, y = blockIdx.x/a.xchunks, z = a.z0+blockIdx.y;
 	if (a.hy && (y == 0u || y == a.Ny-1u)) return;
 	const uint32_t x = (chunk*blockDim.x+threadIdx.x)*V, lane = threadIdx.x&63u;
 	const bool inrow = x < a.Nx; // lanes past the row end stay for the shuffles but touch no memory
@@ -290,19 +214,19 @@ __global__ __launch_bounds__(256, (P == 2 && V == 2 ? 3 : 1)) void k_collide_wid
 	if (inrow) {
 		{
 			const uint32_t o = fresh(xb);
-			d[0] = ld<rvec>(pa[0], o);
+			d[0] = ld_ddf<rvec, MEM>(pa[0], o);
 			static_for<1, Q, 2>([&](auto I) {
-				d[I] = ld<rvec>(own_row(I), o);
-				d[I+1] = ld<rvec>(neighbour_row(I), o); // cells x..x+V-1 of the neighbour row; shifted below when cx != 0
+				d[I] = ld_ddf<rvec, MEM>(own_row(I), o);
+				d[I+1] = ld_ddf<rvec, MEM>(neighbour_row(I), o); // cells x..x+V-1 of the neighbour row; shifted below when cx != 0
 			});
 		}
 		if (seam_hi) {
 			const uint32_t o = fresh(xhib);
-			static_for<1, Q, 2>([&](auto I) { if constexpr (dir<Q>(I,0) > 0) seam[I+1] = ld<raw>(neighbour_row(I), o); });
+			static_for<1, Q, 2>([&](auto I) { if constexpr (dir<Q>(I,0) > 0) seam[I+1] = ld_ddf<raw, MEM>(neighbour_row(I), o); });
 		}
 		if (seam_lo) {
 			const uint32_t o = fresh(xlob);
-			static_for<1, Q, 2>([&](auto I) { if constexpr (dir<Q>(I,0) < 0) seam[I+1] = ld<raw>(neighbour_row(I), o); });
+			static_for<1, Q, 2>([&](auto I) { if constexpr (dir<Q>(I,0) < 0) seam[I+1] = ld_ddf<raw, MEM>(neighbour_row(I), o); });
 		}
 	}
 	static_for<1, Q, 2>([&](auto I) {
@@ -442,10 +366,10 @@ __global__ __launch_bounds__(256, (P == 2 && V == 2 ? 3 : 1)) void k_collide_wid
 	if (!inrow) return;
 	{ // own slots and the neighbour slots of directions without x component: whole aligned vectors
 		const uint32_t o = fresh(xb);
-		st(pa[0], o, d[0]);
+		st_ddf<MEM>(pa[0], o, d[0]);
 		static_for<1, Q, 2>([&](auto I) {
-			st(own_row(I), o, d[I]);
-			if constexpr (dir<Q>(I,0) == 0) st(neighbour_row(I), o, d[I+1]);
+			st_ddf<MEM>(own_row(I), o, d[I]);
+			if constexpr (dir<Q>(I,0) == 0) st_ddf<MEM>(neighbour_row(I), o, d[I+1]);
 		});
 	}
 	// directions with c_x > 0: d[i+1] holds cells x+1..x+V
@@ -458,7 +382,7 @@ __global__ __launch_bounds__(256, (P == 2 && V == 2 ? 3 : 1)) void k_collide_wid
 				t[0] = (raw)carry[i+1];
 #pragma unroll
 				for (int v = 1; v < V; v++) t[v] = d[i+1][v-1];
-				st(neighbour_row(I), o, t);
+				st_ddf<MEM>(neighbour_row(I), o, t);
 			}
 		});
 	} else { // cell x comes from the previous wave's last lane
@@ -467,13 +391,13 @@ __global__ __launch_bounds__(256, (P == 2 && V == 2 ? 3 : 1)) void k_collide_wid
 			constexpr int i = I;
 			if constexpr (dir<Q>(i,0) > 0) {
 #pragma unroll
-				for (int v = 1; v < V; v++) st(neighbour_row(I), o+(uint32_t)v*RB, (raw)d[i+1][v-1]);
+				for (int v = 1; v < V; v++) st_ddf<MEM>(neighbour_row(I), o+(uint32_t)v*RB, (raw)d[i+1][v-1]);
 			}
 		});
 	}
 	if (seam_hi) {
 		const uint32_t o = fresh(xhib);
-		static_for<1, Q, 2>([&](auto I) { constexpr int i = I; if constexpr (dir<Q>(i,0) > 0) st(neighbour_row(I), o, (raw)d[i+1][V-1]); });
+		static_for<1, Q, 2>([&](auto I) { constexpr int i = I; if constexpr (dir<Q>(i,0) > 0) st_ddf<MEM>(neighbour_row(I), o, (raw)d[i+1][V-1]); });
 	}
 	// directions with c_x < 0: d[i+1] holds cells x-1..x+V-2
 	if (!seam_hi) {
@@ -485,7 +409,7 @@ __global__ __launch_bounds__(256, (P == 2 && V == 2 ? 3 : 1)) void k_collide_wid
 #pragma unroll
 				for (int v = 0; v+1 < V; v++) t[v] = d[i+1][v+1];
 				t[V-1] = (raw)carry[i+1];
-				st(neighbour_row(I), o, t);
+				st_ddf<MEM>(neighbour_row(I), o, t);
 			}
 		});
 	} else { // cell x+V-1 comes from the next wave's first lane
@@ -494,13 +418,101 @@ __global__ __launch_bounds__(256, (P == 2 && V == 2 ? 3 : 1)) void k_collide_wid
 			constexpr int i = I;
 			if constexpr (dir<Q>(i,0) < 0) {
 #pragma unroll
-				for (int v = 0; v+1 < V; v++) st(neighbour_row(I), o+(uint32_t)v*RB, (raw)d[i+1][v+1]);
+				for (int v = 0; v+1 < V; v++) st_ddf<MEM>(neighbour_row(I), o+(uint32_t)v*RB, (raw)d[i+1][v+1]);
 			}
 		});
 	}
 	if (seam_lo) {
 		const uint32_t o = fresh(xlob);
-		static_for<1, Q, 2>([&](auto I) { constexpr int i = I; if constexpr (dir<Q>(i,0) < 0) st(neighbour_row(I), o, (raw)d[i+1][0]); });
+		static_for<1, Q, 2>([&](auto I) { constexpr int i = I; if constexpr (dir<Q>(i,0) < 0) st_ddf<MEM>(neighbour_row(I), o, (raw)d[i+1][0]); });
+	}
+}
+
+template <int Q, int ST, int COLL, int FEAT, int V, int P, bool FO = false>
+__global__ __launch_bounds__(256, (P == 2 && V == 2 ? 3 : 1)) void k_collide_wide(const Args a) { // two cells in packed arithmetic: at least 3 waves per SIMD (at most 168 registers; 4 cells per lane would spill)
+	collide_row_wide<Q, ST, COLL, FEAT, V, P, FO>(a, blockIdx.x%a.xchunks, blockIdx.x/a.xchunks, a.z0+blockIdx.y);
+}
+
+// ---------------------------------------------------------------------------------------------- two time steps in one launch
+// k_collide_pair runs step t and step t+1 of a lattice that is periodic in z (no halo) in ONE launch, step t+1 trailing
+// step t by a few planes, so that step t+1 finds the DDFs step t wrote in the 256 MiB Infinity Cache instead of in HBM
+// (the reference launches one kernel per step, lbm.cpp:1411-1459; the result is the same bits, since every cell still
+// sees exactly the values the previous step left).
+//   Order of work (blockIdx.y = plane task, dispatched in ascending order): step t on planes 0..lag+1, then alternately
+//   step t+1 on plane p and step t on plane p+lag, at the end step t+1 on the planes next to the periodic seam
+//   (Nz-lag .. Nz-1, 0, 1).  A workgroup works on one row chunk of one step: with both steps' rows in one workgroup the
+//   second step's loads would queue behind the drain of the first step's stores (measured: 67 % of 8 TB/s against 78 %
+//   with nothing waiting at all).
+//   Dependence: a cell of step t+1 in plane p touches slots in planes p-1..p+1, whose step-t owners sit in planes p-2..p+2
+//   (esoteric-pull: a slot belongs to the cell at its place or to the cell one step against c_i, kernel.cpp:1332-1345).
+//   Every step-t workgroup counts itself done (a counter per plane and shard; the last arriver of a shard reports to the
+//   plane's word), every step-t+1 workgroup waits until the five planes p-2..p+2 have all their shards reported.  With
+//   lag >= 3 a workgroup only ever waits for workgroups with smaller grid indices, which have been dispatched before it.
+//   The wait is bounded: when it runs out the workgroup sets *error and goes on (the host then reports the failure).
+//   Visibility between workgroups of the launch (per-XCD L2s are not coherent, a CU's L1 is never refreshed): step t
+//   stores its DDFs written through at agent scope, drains them (s_waitcnt vmcnt(0) in every wave, then a workgroup
+//   barrier) before one lane counts the workgroup done with an agent-scope atomic; step t+1 polls with agent-scope loads,
+//   passes a workgroup barrier and loads its DDFs at agent scope.  Step t+1 stores plainly: the next launch reads that.
+//   Step t never reads a byte written in this launch (it runs ahead of step t+1 by more than the two planes step t+1
+//   writes beyond its own), so its loads are plain.
+// Not for UPDATE_FIELDS (both steps would write rho/u of a cell from different XCDs with no order between the write-backs).
+struct PairArgs {
+	uint32_t* plane_done; // PAIR_REPLICAS arrays, replica_stride words apart, of Nz words: shards of the plane that have reported (zeroed before the launch)
+	uint32_t replica_stride;
+	uint32_t* shard_done; // Nz*PAIR_SHARDS counters, 64 bytes apart (zeroed before the launch)
+	uint32_t* error;      // set to 1 by a wait that ran out
+	uint32_t lag;         // >= 3
+	uint32_t spin_limit;  // polls before a wait gives up
+};
+// The plane words are kept in PAIR_REPLICAS copies on cache lines of their own: every waiting workgroup of a plane asks
+// about the same five words, and a thousand workgroups asking one line queue up at its memory channel.
+constexpr uint32_t PAIR_SHARDS = 8u, PAIR_SHARD_STRIDE = 16u, PAIR_REPLICAS = 16u;
+// V = 1: the rows of k_collide; V = 2 (16-bit DDFs): the rows of k_collide_wide, P cells collided together.
+template <int Q, int ST, int COLL, int FEAT, int V = 1, int P = 1>
+__global__ __launch_bounds__(256, (P == 2 && V == 2 ? 3 : 1)) void k_collide_pair(const Args a, const PairArgs p) {
+	const uint32_t Nz = a.Nz, lag = p.lag, task = blockIdx.y, per_plane = gridDim.x, in_plane = blockIdx.x;
+	const uint32_t ahead = lag+2u, paired = 2u*(Nz-lag-2u);
+	uint32_t z, second = 0u;
+	if (task < ahead) z = task;
+	else if (task < ahead+paired) { const uint32_t k = task-ahead; second = (k&1u)^1u; z = second ? 2u+k/2u : ahead+k/2u; }
+	else { second = 1u; z = Nz-lag+(task-ahead-paired); if (z >= Nz) z -= Nz; }
+	const uint32_t chunk = in_plane%a.xchunks, y = in_plane/a.xchunks;
+	if (!second) {
+		if constexpr (V == 1) collide_row<Q, ST, COLL, FEAT, false, MEM_STORE_THROUGH>(a, chunk, y, z);
+		else collide_row_wide<Q, ST, COLL, FEAT, V, P, false, MEM_STORE_THROUGH>(a, chunk, y, z);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's stores have been acknowledged
+		__syncthreads();
+		if (threadIdx.x < 64u) {
+			const uint32_t shard = in_plane%PAIR_SHARDS, members = per_plane/PAIR_SHARDS+(shard < per_plane%PAIR_SHARDS ? 1u : 0u);
+			uint32_t before = 0u;
+			if (threadIdx.x == 0u) before = __hip_atomic_fetch_add(p.shard_done+((uint64_t)z*PAIR_SHARDS+shard)*PAIR_SHARD_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const bool last = __shfl((int)(before+1u == members), 0) != 0; // the shard's last arriver reports to every replica of the plane's word
+			if (last && threadIdx.x < PAIR_REPLICAS) __hip_atomic_fetch_add(p.plane_done+(uint64_t)threadIdx.x*p.replica_stride+z, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+	} else {
+		// the row's flags (never written by a step) are fetched while the question below is under way
+		const uint32_t x = (chunk*blockDim.x+threadIdx.x)*(uint32_t)V;
+		uint32_t early = 0u;
+		if (x < a.Nx) early = ld<uint8_t>(a.flags+((uint64_t)z*a.Ny+y)*a.Nx, x);
+		if (threadIdx.x < 64u) {
+			const uint32_t lane = threadIdx.x, shards = per_plane < PAIR_SHARDS ? per_plane : PAIR_SHARDS; // shards without members never report
+			const uint32_t zz = (z+Nz-2u+(lane < 5u ? lane : 0u))%Nz;
+			for (uint32_t spins = 0u; ; spins++) {
+				bool ok = true;
+				if (lane < 5u) ok = __hip_atomic_load(p.plane_done+(uint64_t)(in_plane%PAIR_REPLICAS)*p.replica_stride+zz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= shards;
+				if (__ballot(!ok) == 0ull) break;
+				if (spins >= p.spin_limit) { if (lane == 0u) __hip_atomic_store(p.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+				if (spins < 2u) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(127); // a workgroup that is ahead of the first step asks rarely: its questions share the memory system with the work it waits for
+			}
+		}
+		__syncthreads();
+		Args b = a;
+		b.odd = a.odd^1u;
+		if constexpr (V == 1) collide_row<Q, ST, COLL, FEAT, false, MEM_LOAD_COHERENT, true>(b, chunk, y, z, early);
+		else {
+			asm volatile("" :: "v"(early)); // the early load has brought the lanes' flag bytes into the cache
+			collide_row_wide<Q, ST, COLL, FEAT, V, P, false, MEM_LOAD_COHERENT>(b, chunk, y, z);
+		}
 	}
 }
 

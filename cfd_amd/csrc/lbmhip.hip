@@ -53,7 +53,7 @@ struct lbmhip_domain {
 	float w;
 	// two time steps per launch (k_collide_pair): completion counters of the first step's workgroups, then one error word
 	uint32_t* pair_sync; uint64_t pair_sync_words; uint32_t pair_replica_stride;
-	int fuse, pair_lag, pair_blocks_per_cu; // fuse: -1 = automatic, 0 = never, 1 = whenever a compiled instance exists; pair_lag 0 = automatic; pair_blocks_per_cu -1 = automatic
+	int fuse, pair_lag, pair_blocks_per_cu, pair_cells_together; // fuse: -1 = automatic, 0 = never, 1 = whenever a compiled instance exists; pair_lag 0 = automatic; pair_blocks_per_cu -1 = automatic
 	int pair_used, pair_used_lag, pair_used_blocks_per_cu, pair_unchecked; // what the last lbmhip_stream_collide_steps call ran; launches since the error word was last read
 	int compute_units;
 };
@@ -273,7 +273,7 @@ int lbmhip_domain_create(const lbmhip_config* c, lbmhip_domain** out) {
 		}
 	}
 	e = hipMalloc(&d->partial, kObjectSumBlocks*4u*sizeof(float));
-	d->fuse = -1; d->pair_lag = 0; d->pair_blocks_per_cu = -1;
+	d->fuse = -1; d->pair_lag = 0; d->pair_blocks_per_cu = -1; d->pair_cells_together = 1;
 	{ const char* env = getenv("LBMHIP_FUSE"); if (env && (env[0] == '0' || env[0] == '1') && !env[1]) d->fuse = env[0]-'0'; }
 	if (e == hipSuccess) e = hipDeviceGetAttribute(&d->compute_units, hipDeviceAttributeMultiprocessorCount, c->device);
 	if (e == hipSuccess && c->Dx*c->Dy*c->Dz == 1u && c->Nz >= 8u) { // what k_collide_pair needs, whether or not it is ever used (264 KB at 512 planes)
@@ -442,6 +442,7 @@ int lbmhip_set_tuning(lbmhip_domain* d, const char* key, int value) {
 	if (!strcmp(key, "autotune")) { NEED(value == 0 || value == 1, "autotune must be 0 or 1"); d->autotune = value; if (!value) { d->tuned = 0; d->tune_launches = 0; d->tune_pending = -1; } return 0; }
 	if (!strcmp(key, "fuse")) { NEED(value >= -1 && value <= 1, "fuse must be -1 (auto), 0 or 1"); d->fuse = value; return 0; }
 	if (!strcmp(key, "pair_lag")) { NEED(value == 0 || (value >= 3 && value <= 64), "pair_lag must be 0 (auto) or 3..64"); d->pair_lag = value; return 0; }
+	if (!strcmp(key, "pair_cells_together")) { NEED(value == 1 || value == 2, "pair_cells_together must be 1 or 2"); d->pair_cells_together = value; return 0; }
 	if (!strcmp(key, "pair_blocks_per_cu")) { NEED(value >= -1 && value <= 32, "pair_blocks_per_cu must be -1 (auto), 0 (no limit) or 1..32"); d->pair_blocks_per_cu = value; return 0; }
 	return fail("unknown tuning key '%s'", key);
 }
@@ -457,6 +458,7 @@ int lbmhip_get_tuning(lbmhip_domain* d, const char* key, int* value) {
 	if (!strcmp(key, "fuse")) { *value = d->fuse; return 0; }
 	if (!strcmp(key, "fused")) { *value = d->pair_used; return 0; } // the last lbmhip_stream_collide_steps call ran two steps per launch
 	if (!strcmp(key, "pair_lag")) { *value = d->pair_used ? d->pair_used_lag : d->pair_lag; return 0; }
+	if (!strcmp(key, "pair_cells_together")) { *value = d->pair_cells_together; return 0; }
 	if (!strcmp(key, "pair_blocks_per_cu")) { *value = d->pair_used ? d->pair_used_blocks_per_cu : d->pair_blocks_per_cu; return 0; }
 	return fail("unknown tuning key '%s'", key);
 }
@@ -680,10 +682,14 @@ int lbmhip_stream_collide(lbmhip_domain* d, uint64_t t, float fx, float fy, floa
 static const uint64_t kPairWindowBytes = 200ull<<20;
 static bool pair_plan(const lbmhip_domain* d, pair_launch_fn* fn, uint32_t* lag, int* blocks_per_cu, uint32_t* xchunks, uint32_t* block) {
 	if (d->fuse == 0 || !d->pair_sync || (d->cfg.features&LBMHIP_UPDATE_FIELDS)) return false;
-	*fn = select_collide_pair((int)d->cfg.velocity_set, (int)d->cfg.storage, (int)d->cfg.collision, (int)d->cfg.features);
+	const bool half = d->cfg.storage != LBMHIP_FP32;
+	const uint32_t V = half ? 2u : 1u; // the agent-scope accesses move 4 bytes per lane: one FP32 cell or two 16-bit cells
+	if (d->cfg.Nx%V != 0u) return false;
+	*fn = select_collide_pair((int)d->cfg.velocity_set, (int)d->cfg.storage, (int)d->cfg.collision, (int)d->cfg.features, (int)V, (V == 2u && d->pair_cells_together == 2) ? 2 : 1);
 	if (!*fn) return false;
-	*block = std::min(256u, (d->cfg.Nx+63u)/64u*64u);
-	*xchunks = (d->cfg.Nx+*block-1u)/(*block);
+	const uint32_t lanes_per_row = d->cfg.Nx/V;
+	*block = std::min(256u, (lanes_per_row+63u)/64u*64u);
+	*xchunks = (lanes_per_row+*block-1u)/(*block);
 	const uint64_t per_plane = (uint64_t)*xchunks*d->cfg.Ny;
 	if (per_plane*(*block) >= 0xFFFFFFFFull || 2u*d->cfg.Nz > 65535u) return false;
 	*blocks_per_cu = d->pair_blocks_per_cu >= 0 ? d->pair_blocks_per_cu : 6;

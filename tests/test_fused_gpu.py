@@ -18,6 +18,8 @@ pytestmark = pytest.mark.gpu
 TGV = dict(N=(96, 64, 48), nu=0.02)
 CHANNEL = dict(N=(320, 64, 40), nu=0.01, features=("VOLUME_FORCE", "SUBGRID"), f=(2e-4, 0.0, 0.0), collision="TRT")
 Q27 = dict(N=(64, 48, 40), nu=0.03, Q=27)
+HALF_S = dict(N=(192, 64, 40), nu=0.02, storage="FP16S")   # 16-bit DDFs: two cells per lane, rows of several waves (seam lanes)
+HALF_C = dict(N=(136, 48, 40), nu=0.02, storage="FP16C")   # a row that ends inside a wave
 
 
 def fused_flag(lbm):
@@ -31,14 +33,15 @@ def bits(a):
 
 
 @pytest.mark.parametrize("lag,cap", [(3, 0), (5, 0), (4, 3), (9, 2)])
-@pytest.mark.parametrize("kw,setup,steps", [(TGV, setups.taylor_green, 7), (CHANNEL, setups.channel, 10), (Q27, setups.taylor_green, 4)])
-def test_paired_steps_equal_single_steps(gpu, kw, setup, steps, lag, cap):
+@pytest.mark.parametrize("kw,setup,steps,together", [(TGV, setups.taylor_green, 7, 1), (CHANNEL, setups.channel, 10, 1), (Q27, setups.taylor_green, 4, 1),
+                                                     (HALF_S, setups.taylor_green, 6, 1), (HALF_S, setups.taylor_green, 5, 2), (HALF_C, setups.taylor_green, 6, 1)])
+def test_paired_steps_equal_single_steps(gpu, kw, setup, steps, together, lag, cap):
     a = cfd_amd.LBM(**kw); b = cfd_amd.LBM(**kw)
     try:
         for lbm, fuse in ((a, 1), (b, 0)):
             lbm.set_tuning("fuse", fuse)
             setup(lbm)
-        a.set_tuning("pair_lag", lag); a.set_tuning("pair_blocks_per_cu", cap)
+        a.set_tuning("pair_lag", lag); a.set_tuning("pair_blocks_per_cu", cap); a.set_tuning("pair_cells_together", together)
         a.run(steps); b.run(steps)
         assert fused_flag(a) == 1 and fused_flag(b) == 0
         assert np.array_equal(bits(a.domains[0].download_fi()), bits(b.domains[0].download_fi())), "DDFs differ"
@@ -51,11 +54,12 @@ def test_paired_steps_equal_single_steps(gpu, kw, setup, steps, lag, cap):
         a.close(); b.close()
 
 
-def test_paired_steps_equal_the_oracle(gpu):
-    a = cfd_amd.LBM(**CHANNEL); b = H.OracleLBM(**CHANNEL)
+@pytest.mark.parametrize("kw,setup", [(CHANNEL, setups.channel), (HALF_S, setups.taylor_green), (HALF_C, setups.taylor_green)])
+def test_paired_steps_equal_the_oracle(gpu, kw, setup):
+    a = cfd_amd.LBM(**kw); b = H.OracleLBM(**kw)
     try:
         a.set_tuning("fuse", 1); a.set_tuning("pair_lag", 3)
-        setups.channel(a); setups.channel(b)
+        setup(a); setup(b)
         a.run(12); b.run(12)
         assert fused_flag(a) == 1
         assert np.array_equal(bits(a.domains[0].download_fi()), bits(b.domains[0].fi)), "DDFs differ from the oracle"
@@ -69,7 +73,7 @@ def test_paired_steps_equal_the_oracle(gpu):
 def test_what_is_never_paired(gpu):
     """UPDATE_FIELDS, several domains, lattices with too few planes and feature sets without an instance run one launch per step."""
     for kw in (dict(N=(64, 64, 48), nu=0.02, features=("UPDATE_FIELDS",)), dict(N=(64, 64, 48), nu=0.02, D=(1, 1, 2)), dict(N=(64, 64, 6), nu=0.02),
-               dict(N=(64, 64, 48), nu=0.02, features=("MOVING_BOUNDARIES",)), dict(N=(64, 64, 48), nu=0.02, storage="FP16S")):
+               dict(N=(64, 64, 48), nu=0.02, features=("MOVING_BOUNDARIES",)), dict(N=(64, 64, 48), nu=0.02, storage="FP16S", collision="TRT"), dict(N=(65, 64, 48), nu=0.02, storage="FP16S")):
         a = cfd_amd.LBM(**kw); b = H.OracleLBM(**kw)
         try:
             a.set_tuning("fuse", 1)
