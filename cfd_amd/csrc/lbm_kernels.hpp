@@ -478,6 +478,7 @@ __global__ __launch_bounds__(256, (P == 2 && V == 2 ? 3 : 1)) void k_collide_pai
 	else { second = 1u; z = Nz-lag+(task-ahead-paired); if (z >= Nz) z -= Nz; }
 	const uint32_t chunk = in_plane%a.xchunks, y = in_plane/a.xchunks;
 	if (!second) {
+		__builtin_amdgcn_s_setprio(2); // the first step is what everything else waits for: its waves issue ahead of the second step's (512^3 FP32: 72.5 -> 77.8 % of 8 TB/s)
 		if constexpr (V == 1) collide_row<Q, ST, COLL, FEAT, false, MEM_STORE_THROUGH>(a, chunk, y, z);
 		else collide_row_wide<Q, ST, COLL, FEAT, V, P, false, MEM_STORE_THROUGH>(a, chunk, y, z);
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's stores have been acknowledged

@@ -672,13 +672,16 @@ int lbmhip_stream_collide(lbmhip_domain* d, uint64_t t, float fx, float fy, floa
 // Two steps per launch: when does it apply, and with which geometry?  The lattice must be one periodic domain (a step
 // between two exchanges cannot be paired), without UPDATE_FIELDS, with a compiled k_collide_pair instance; and the planes
 // that lie between the two steps (lag + 4 of them) must fit the Infinity Cache with room to spare, else the second step
-// reads from HBM like a launch of its own and only the waiting is left.  lag = 3 + the whole planes the resident
-// workgroups cover: the second step then asks for planes whose workgroups have left, and its question costs one memory
-// round trip instead of a wait.  Measured at 512^3 D3Q19 FP32 (20 MB planes, tools/fused_sweep.py): at most 6 workgroups
-// per CU and lag 4 (72.5 % of 8 TB/s against 68.4 % with a launch per step; lag 3: 62 %, lag 6: 69 %; no cap, lag 5: 70 %).
-// Automatic mode (fuse = -1) pairs only where it was measured to pay: plain D3Q19 SRT with FP32 DDFs and planes of at
-// least 1024 workgroups (512^3: 38 100 against 35 900 MLUPs/s; 384^3 and 256^3 lose 5-8 %, their planes are a fraction of
-// what is resident; the TRT + subgrid channel kernel, 3 workgroups per CU, loses 5 %).  fuse = 1 pairs whenever it can.
+// reads from HBM like a launch of its own and only the waiting is left.  lag = 2 + the planes the resident workgroups
+// cover, rounded up: the second step then asks for planes whose workgroups have left.  Measured at 512^3
+// D3Q19 FP32 (20 MB planes, tools/fused_sweep.py): no residency cap and lag 4 (77.8 % of 8 TB/s against 68.3 % with a launch
+// per step; lag 3: 70 %, lag 5: 75.5 %, lag 8: 66 %).
+// Automatic mode (fuse = -1) pairs only where it was measured to pay (tools/fused_sweep.py, MI355X): plain D3Q19 SRT on
+// planes of at least 512 x 512 cells made of whole 256-lane chunks - 512^3 FP32 40 700 against 35 700 MLUPs/s (77.8 against
+// 68.3 % of 8 TB/s), FP16S 74 900 against 67 200 (72.1 against 64.6 %).  Smaller planes are a fraction of what is resident on
+// the chip, the lag in planes grows and the best residency cap changes (256^3: 73 against 69 % with at most 6 workgroups
+// per CU, 67 % without a cap; 384^3, whose rows end in a half-empty chunk: 63 against 65 %); the TRT + subgrid channel
+// kernel (132 registers, 3 workgroups per CU) loses 5 %.  fuse = 1 pairs whenever it can.
 static const uint64_t kPairWindowBytes = 200ull<<20;
 static bool pair_plan(const lbmhip_domain* d, pair_launch_fn* fn, uint32_t* lag, int* blocks_per_cu, uint32_t* xchunks, uint32_t* block) {
 	if (d->fuse == 0 || !d->pair_sync || (d->cfg.features&LBMHIP_UPDATE_FIELDS)) return false;
@@ -692,13 +695,13 @@ static bool pair_plan(const lbmhip_domain* d, pair_launch_fn* fn, uint32_t* lag,
 	*xchunks = (lanes_per_row+*block-1u)/(*block);
 	const uint64_t per_plane = (uint64_t)*xchunks*d->cfg.Ny;
 	if (per_plane*(*block) >= 0xFFFFFFFFull || 2u*d->cfg.Nz > 65535u) return false;
-	*blocks_per_cu = d->pair_blocks_per_cu >= 0 ? d->pair_blocks_per_cu : 6;
+	*blocks_per_cu = d->pair_blocks_per_cu >= 0 ? d->pair_blocks_per_cu : 0;
 	const uint64_t resident = (uint64_t)d->compute_units*(uint64_t)(*blocks_per_cu > 0 ? std::min(*blocks_per_cu*256/(int)*block, 8*256/(int)*block) : 8*256/(int)*block);
-	*lag = d->pair_lag ? (uint32_t)d->pair_lag : 3u+(uint32_t)(resident/per_plane);
+	*lag = d->pair_lag ? (uint32_t)d->pair_lag : std::max(3u, 2u+(uint32_t)((resident+per_plane-1u)/per_plane));
 	if (d->cfg.Nz < *lag+4u) return false;
 	const uint64_t plane_bytes = (uint64_t)d->cfg.Nx*d->cfg.Ny*d->cfg.velocity_set*d->fpxx_bytes;
-	if (d->fuse < 0 && ((uint64_t)(*lag+4u)*plane_bytes > kPairWindowBytes || per_plane < 1024u || d->cfg.velocity_set != 19u || d->cfg.storage != LBMHIP_FP32 ||
-	                    d->cfg.collision != LBMHIP_SRT || d->cfg.features != 0u)) return false;
+	if (d->fuse < 0 && ((uint64_t)(*lag+4u)*plane_bytes > kPairWindowBytes || (uint64_t)d->cfg.Nx*d->cfg.Ny < 512ull*512ull || lanes_per_row%256u != 0u ||
+	                    d->cfg.velocity_set != 19u || d->cfg.collision != LBMHIP_SRT || d->cfg.features != 0u)) return false;
 	return true;
 }
 static int launch_collide_pair_steps(lbmhip_domain* d, pair_launch_fn fn, uint64_t t, float fx, float fy, float fz, uint32_t lag, int blocks_per_cu, uint32_t xchunks, uint32_t block) {

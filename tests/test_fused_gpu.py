@@ -88,7 +88,7 @@ def test_what_is_never_paired(gpu):
 
 def test_large_planes_pair_only_on_request(gpu):
     """Automatic mode leaves lattices alone whose planes between the two steps would not fit the cache."""
-    kw = dict(N=(2048, 1024, 16), nu=0.02)
+    kw = dict(N=(2048, 1024, 16), nu=0.02)  # 160 MB planes
     a = cfd_amd.LBM(**kw)
     try:
         setups.taylor_green(a)
