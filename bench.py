@@ -194,6 +194,7 @@ def main():
 
     if a.no_fuse:
         check(lib.lbmhip_set_tuning(lbm.ops.dom.h, b"fuse", 0))
+        lbm.pair_steps = False
     # untimed: the library tries its launch geometries on the first full-lattice launches and keeps the fastest
     # (a lattice whose steps are paired needs no search: the odd step of a call at most runs the single-step kernel)
     tuned, fused = C.c_int(0), C.c_int(0)
@@ -208,11 +209,7 @@ def main():
     ms_events = C.c_float()
     t0 = time.perf_counter()
     check(lib.lbmhip_timer_start(lbm.ops.dom.h))          # HIP events on the stream the kernels are launched on
-    if world == 1:
-        lbm.run(a.steps)                                  # one lbmhip_stream_collide_steps call for the K steps
-    else:
-        for _ in range(a.steps):
-            lbm.do_time_step()
+    lbm.run(a.steps)   # one rank: one lbmhip_stream_collide_steps call; slabs: the steps two at a time around the halo exchanges (DistributedLBM.run)
     check(lib.lbmhip_timer_stop(lbm.ops.dom.h, C.byref(ms_events)))
     barrier()
     own_seconds = time.perf_counter() - t0

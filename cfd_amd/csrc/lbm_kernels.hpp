@@ -438,9 +438,10 @@ __global__ __launch_bounds__(256, (P == 2 && V == 2 ? 3 : 1)) void k_collide_wid
 // step t by a few planes, so that step t+1 finds the DDFs step t wrote in the 256 MiB Infinity Cache instead of in HBM
 // (the reference launches one kernel per step, lbm.cpp:1411-1459; the result is the same bits, since every cell still
 // sees exactly the values the previous step left).
-//   Order of work (blockIdx.y = plane task, dispatched in ascending order): step t on planes 0..lag+1, then alternately
-//   step t+1 on plane p and step t on plane p+lag, at the end step t+1 on the planes next to the periodic seam
-//   (Nz-lag .. Nz-1, 0, 1).  A workgroup works on one row chunk of one step: with both steps' rows in one workgroup the
+//   Order of work (blockIdx.y = plane task, dispatched in ascending order), for the whole periodic lattice: step t on
+//   planes 0..lag+1, then alternately step t+1 on plane p and step t on plane p+lag, at the end step t+1 on the planes next
+//   to the periodic seam (Nz-lag .. Nz-1, 0, 1).  PairArgs describes the general form (two plane ranges), which also
+//   covers the inner planes of a z-slab between two halo exchanges.  A workgroup works on one row chunk of one step: with both steps' rows in one workgroup the
 //   second step's loads would queue behind the drain of the first step's stores (measured: 67 % of 8 TB/s against 78 %
 //   with nothing waiting at all).
 //   Dependence: a cell of step t+1 in plane p touches slots in planes p-1..p+1, whose step-t owners sit in planes p-2..p+2
@@ -463,6 +464,11 @@ struct PairArgs {
 	uint32_t* error;      // set to 1 by a wait that ran out
 	uint32_t lag;         // >= 3
 	uint32_t spin_limit;  // polls before a wait gives up
+	// Step t runs on the planes first1 .. first1+count1-1, step t+1 on first2 .. first2+count2-1 (taken modulo Nz).  The whole
+	// periodic lattice: first1 = 0, count1 = Nz, first2 = 2, count2 = Nz (planes 0 and 1 come last).  The inner planes of a
+	// z-slab whose planes next to the halos are stepped by launches of their own: first2 = first1+2, count2 = count1-4, so
+	// that every plane a step-t+1 cell depends on (p-2 .. p+2) belongs to this launch's step t.
+	uint32_t first1, count1, first2, count2;
 };
 // The plane words are kept in PAIR_REPLICAS copies on cache lines of their own: every waiting workgroup of a plane asks
 // about the same five words, and a thousand workgroups asking one line queue up at its memory channel.
@@ -470,12 +476,16 @@ constexpr uint32_t PAIR_SHARDS = 8u, PAIR_SHARD_STRIDE = 16u, PAIR_REPLICAS = 16
 // V = 1: the rows of k_collide; V = 2 (16-bit DDFs): the rows of k_collide_wide, P cells collided together.
 template <int Q, int ST, int COLL, int FEAT, int V = 1, int P = 1>
 __global__ __launch_bounds__(256, (P == 2 && V == 2 ? 3 : 1)) void k_collide_pair(const Args a, const PairArgs p) {
-	const uint32_t Nz = a.Nz, lag = p.lag, task = blockIdx.y, per_plane = gridDim.x, in_plane = blockIdx.x;
-	const uint32_t ahead = lag+2u, paired = 2u*(Nz-lag-2u);
+	const uint32_t Nz = a.Nz, task = blockIdx.y, per_plane = gridDim.x, in_plane = blockIdx.x;
+	// step t+1 on plane first2+j follows step t on plane first2+j+lag-1: `ahead` planes of step t come first, then the two
+	// alternate, then whichever step still has planes left finishes (gridDim.y = count1+count2)
+	const uint32_t ahead = min(p.count1, p.first2+p.lag-p.first1), both = min(p.count1-ahead, p.count2);
 	uint32_t z, second = 0u;
-	if (task < ahead) z = task;
-	else if (task < ahead+paired) { const uint32_t k = task-ahead; second = (k&1u)^1u; z = second ? 2u+k/2u : ahead+k/2u; }
-	else { second = 1u; z = Nz-lag+(task-ahead-paired); if (z >= Nz) z -= Nz; }
+	if (task < ahead) z = p.first1+task;
+	else if (task < ahead+2u*both) { const uint32_t k = task-ahead; second = (k&1u)^1u; z = second ? p.first2+k/2u : p.first1+ahead+k/2u; }
+	else if (ahead+both < p.count1) z = p.first1+ahead+both+(task-ahead-2u*both); // step t+1 has run out of planes first
+	else { second = 1u; z = p.first2+both+(task-ahead-2u*both); }
+	if (z >= Nz) z -= Nz;
 	const uint32_t chunk = in_plane%a.xchunks, y = in_plane/a.xchunks;
 	if (!second) {
 		__builtin_amdgcn_s_setprio(2); // the first step is what everything else waits for: its waves issue ahead of the second step's (512^3 FP32: 72.5 -> 77.8 % of 8 TB/s)
@@ -498,9 +508,10 @@ __global__ __launch_bounds__(256, (P == 2 && V == 2 ? 3 : 1)) void k_collide_pai
 		if (threadIdx.x < 64u) {
 			const uint32_t lane = threadIdx.x, shards = per_plane < PAIR_SHARDS ? per_plane : PAIR_SHARDS; // shards without members never report
 			const uint32_t zz = (z+Nz-2u+(lane < 5u ? lane : 0u))%Nz;
+			const bool asked = (zz+Nz-p.first1)%Nz < p.count1; // planes outside this launch's step t were finished by earlier launches
 			for (uint32_t spins = 0u; ; spins++) {
 				bool ok = true;
-				if (lane < 5u) ok = __hip_atomic_load(p.plane_done+(uint64_t)(in_plane%PAIR_REPLICAS)*p.replica_stride+zz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= shards;
+				if (lane < 5u && asked) ok = __hip_atomic_load(p.plane_done+(uint64_t)(in_plane%PAIR_REPLICAS)*p.replica_stride+zz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= shards;
 				if (__ballot(!ok) == 0ull) break;
 				if (spins >= p.spin_limit) { if (lane == 0u) __hip_atomic_store(p.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
 				if (spins < 2u) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(127); // a workgroup that is ahead of the first step asks rarely: its questions share the memory system with the work it waits for

@@ -276,7 +276,7 @@ int lbmhip_domain_create(const lbmhip_config* c, lbmhip_domain** out) {
 	d->fuse = -1; d->pair_lag = 0; d->pair_blocks_per_cu = -1; d->pair_cells_together = 1;
 	{ const char* env = getenv("LBMHIP_FUSE"); if (env && (env[0] == '0' || env[0] == '1') && !env[1]) d->fuse = env[0]-'0'; }
 	if (e == hipSuccess) e = hipDeviceGetAttribute(&d->compute_units, hipDeviceAttributeMultiprocessorCount, c->device);
-	if (e == hipSuccess && c->Dx*c->Dy*c->Dz == 1u && c->Nz >= 8u) { // what k_collide_pair needs, whether or not it is ever used (264 KB at 512 planes)
+	if (e == hipSuccess && c->Dx == 1u && c->Dy == 1u && c->Nz >= 8u) { // what k_collide_pair needs, whether or not it is ever used (264 KB at 512 planes)
 		d->pair_replica_stride = (c->Nz+63u)/64u*64u+32u; // the replicas start on different cache lines, an odd number of lines apart
 		d->pair_sync_words = (uint64_t)PAIR_REPLICAS*d->pair_replica_stride+(uint64_t)c->Nz*PAIR_SHARDS*PAIR_SHARD_STRIDE+16u;
 		e = hipMalloc((void**)&d->pair_sync, d->pair_sync_words*sizeof(uint32_t));
@@ -684,7 +684,7 @@ int lbmhip_stream_collide(lbmhip_domain* d, uint64_t t, float fx, float fy, floa
 // kernel (132 registers, 3 workgroups per CU) loses 5 %.  fuse = 1 pairs whenever it can.
 static const uint64_t kPairWindowBytes = 200ull<<20;
 static bool pair_plan(const lbmhip_domain* d, pair_launch_fn* fn, uint32_t* lag, int* blocks_per_cu, uint32_t* xchunks, uint32_t* block) {
-	if (d->fuse == 0 || !d->pair_sync || (d->cfg.features&LBMHIP_UPDATE_FIELDS)) return false;
+	if (d->fuse == 0 || !d->pair_sync || (d->cfg.features&LBMHIP_UPDATE_FIELDS) || d->cfg.Dx != 1u || d->cfg.Dy != 1u) return false;
 	const bool half = d->cfg.storage != LBMHIP_FP32;
 	const uint32_t V = half ? 2u : 1u; // the agent-scope accesses move 4 bytes per lane: one FP32 cell or two 16-bit cells
 	if (d->cfg.Nx%V != 0u) return false;
@@ -704,17 +704,19 @@ static bool pair_plan(const lbmhip_domain* d, pair_launch_fn* fn, uint32_t* lag,
 	                    d->cfg.velocity_set != 19u || d->cfg.collision != LBMHIP_SRT || d->cfg.features != 0u)) return false;
 	return true;
 }
-static int launch_collide_pair_steps(lbmhip_domain* d, pair_launch_fn fn, uint64_t t, float fx, float fy, float fz, uint32_t lag, int blocks_per_cu, uint32_t xchunks, uint32_t block) {
+static int launch_collide_pair_steps(lbmhip_domain* d, pair_launch_fn fn, uint64_t t, float fx, float fy, float fz, uint32_t lag, int blocks_per_cu, uint32_t xchunks, uint32_t block,
+                                     uint32_t first1, uint32_t count1, uint32_t first2, uint32_t count2) {
 	DeviceGuard g(d->cfg.device);
 	Args a = make_args(d, t, fx, fy, fz);
 	a.xchunks = xchunks; a.z0 = 0u; a.z1 = d->cfg.Nz;
 	PairArgs p;
+	p.first1 = first1; p.count1 = count1; p.first2 = first2; p.count2 = count2;
 	p.plane_done = d->pair_sync; p.replica_stride = d->pair_replica_stride; p.shard_done = d->pair_sync+(uint64_t)PAIR_REPLICAS*d->pair_replica_stride; p.error = d->pair_sync+d->pair_sync_words-16u;
 	p.lag = lag; p.spin_limit = 500000u; // about two seconds of polling (3.4 us of sleep between two polls)
 	HIP_TRY(hipMemsetAsync(d->pair_sync, 0, (d->pair_sync_words-16u)*sizeof(uint32_t), d->stream));
 	if (blocks_per_cu > 0) blocks_per_cu = std::max(1, blocks_per_cu*256/(int)block);
 	const uint32_t lds = blocks_per_cu > 0 ? ((160u*1024u/(uint32_t)blocks_per_cu)&~255u) : 0u;
-	HIP_TRY(fn(a, p, dim3(xchunks*d->cfg.Ny, 2u*d->cfg.Nz), dim3(block), lds, d->stream));
+	HIP_TRY(fn(a, p, dim3(xchunks*d->cfg.Ny, count1+count2), dim3(block), lds, d->stream));
 	d->pair_unchecked = 1;
 	return 0;
 }
@@ -724,12 +726,30 @@ int lbmhip_stream_collide_steps(lbmhip_domain* d, uint64_t t, uint32_t steps, fl
 	uint32_t lag = 0u, xchunks = 1u, block = 256u, done = 0u;
 	int blocks_per_cu = 0;
 	d->pair_used = 0;
-	if (steps >= 2u && pair_plan(d, &fn, &lag, &blocks_per_cu, &xchunks, &block)) {
-		for (; steps-done >= 2u; done += 2u) { const int status = launch_collide_pair_steps(d, fn, t+done, fx, fy, fz, lag, blocks_per_cu, xchunks, block); if (status) return status; }
+	if (steps >= 2u && d->cfg.Dz == 1u && pair_plan(d, &fn, &lag, &blocks_per_cu, &xchunks, &block)) {
+		for (; steps-done >= 2u; done += 2u) { const int status = launch_collide_pair_steps(d, fn, t+done, fx, fy, fz, lag, blocks_per_cu, xchunks, block, 0u, d->cfg.Nz, 2u, d->cfg.Nz); if (status) return status; }
 		d->pair_used = 1; d->pair_used_lag = (int)lag; d->pair_used_blocks_per_cu = blocks_per_cu;
 	}
 	for (; done < steps; done++) { const int status = launch_collide_planes(d, t+done, fx, fy, fz, 0u, d->cfg.Nz, false); if (status) return status; }
 	return 0;
+}
+int lbmhip_stream_collide_pair_planes(lbmhip_domain* d, uint64_t t, float fx, float fy, float fz, uint32_t z_begin, uint32_t z_end) {
+	NEED(d, "null domain");
+	NEED(z_begin <= z_end && z_end <= d->cfg.Nz, "plane range [%u, %u) outside the lattice (Nz=%u)", z_begin, z_end, d->cfg.Nz);
+	NEED(d->cfg.Dz == 1u || (z_begin >= 1u && z_end <= d->cfg.Nz-1u), "plane range [%u, %u) includes a halo plane", z_begin, z_end);
+	pair_launch_fn fn = nullptr;
+	uint32_t lag = 0u, xchunks = 1u, block = 256u;
+	int blocks_per_cu = 0;
+	d->pair_used = 0;
+	if (z_end-z_begin >= 5u && pair_plan(d, &fn, &lag, &blocks_per_cu, &xchunks, &block) && z_end-z_begin >= lag+6u) {
+		const int status = launch_collide_pair_steps(d, fn, t, fx, fy, fz, lag, blocks_per_cu, xchunks, block, z_begin, z_end-z_begin, z_begin+2u, z_end-z_begin-4u);
+		if (status) return status;
+		d->pair_used = 1; d->pair_used_lag = (int)lag; d->pair_used_blocks_per_cu = blocks_per_cu;
+		return 0;
+	}
+	int status = launch_collide_planes(d, t, fx, fy, fz, z_begin, z_end, false);
+	if (!status && z_end-z_begin > 4u) status = launch_collide_planes(d, t+1u, fx, fy, fz, z_begin+2u, z_end-2u, false);
+	return status;
 }
 int lbmhip_stream_collide_planes(lbmhip_domain* d, uint64_t t, float fx, float fy, float fz, uint32_t z_begin, uint32_t z_end) {
 	NEED(d, "null domain");

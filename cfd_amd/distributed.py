@@ -40,6 +40,9 @@ class SlabOps:
     def download(self, names): raise NotImplementedError
     def initialize(self): raise NotImplementedError
     def collide_planes(self, t, f, z0, z1): raise NotImplementedError
+    def collide_pair_planes(self, t, f, z0, z1):  # step t on [z0, z1) and step t+1 on [z0+2, z1-2), which depends on nothing else
+        self.collide_planes(t, f, z0, z1)
+        self.collide_planes(t + 1, f, z0 + 2, z1 - 2)
     def collide_steps(self, t, f, steps):  # `steps` whole-lattice steps with nothing in between (a single rank only)
         for k in range(steps):
             self.collide_planes(t + k, f, 0, self.local[2])
@@ -117,6 +120,9 @@ class HipSlabOps(SlabOps):
 
     def collide_planes(self, t, f, z0, z1):
         L.check(self.lib.lbmhip_stream_collide_planes(self.dom.h, C.c_uint64(t), C.c_float(f[0]), C.c_float(f[1]), C.c_float(f[2]), int(z0), int(z1)))
+
+    def collide_pair_planes(self, t, f, z0, z1):
+        L.check(self.lib.lbmhip_stream_collide_pair_planes(self.dom.h, C.c_uint64(t), C.c_float(f[0]), C.c_float(f[1]), C.c_float(f[2]), int(z0), int(z1)))
 
     def collide_steps(self, t, f, steps):
         L.check(self.lib.lbmhip_stream_collide_steps(self.dom.h, C.c_uint64(t), C.c_uint32(steps), C.c_float(f[0]), C.c_float(f[1]), C.c_float(f[2])))
@@ -201,6 +207,7 @@ class DistributedLBM:
         self.initialized = False
         self.t_last_update_fields = None
         self.overlap = bool(overlap) and self.world > 1 and self.local[2] >= 5
+        self.pair_steps = True  # run() takes the steps of a slab two at a time (_do_two_time_steps)
         self.next = (self.rank + 1) % self.world
         self.prev = (self.rank - 1) % self.world
         self._host_staging = None
@@ -310,10 +317,42 @@ class DistributedLBM:
         if self.update_fields_ext:
             self.t_last_update_fields = self.t
 
+    def _do_two_time_steps(self):
+        """Steps t and t+1 of a slab with one exchange hidden and one exposed instead of two hidden ones, so that the engine can
+        run the inner planes of both steps in one launch (lbmhip_stream_collide_pair_planes):
+          step t on the planes next to the halos, exchange t                          (communication stream)
+          step t on the planes 2 .. Lz-3 and step t+1 on the planes 4 .. Lz-5        (compute stream, beside the exchange)
+          step t+1 on the planes 1..3 and Lz-4..Lz-2, which need the halos of step t  (compute stream, after the exchange)
+          exchange t+1
+        A cell of step t+1 in plane p depends on step t in the planes p-2 .. p+2, so the planes 4 .. Lz-5 need nothing from a
+        halo; every cell still sees exactly the values of the step before (same bits as two calls of _do_time_step)."""
+        Lz = self.local[2]
+        o = self.ops
+        o.fork()
+        try:
+            o.collide_planes(self.t, self.f, 1, 2)
+            o.collide_planes(self.t, self.f, Lz - 2, Lz - 1)
+            self._communicate("fi")
+        finally:
+            o.end_fork()
+        o.collide_pair_planes(self.t, self.f, 2, Lz - 2)
+        o.join()
+        self.t += 1
+        o.collide_planes(self.t, self.f, 1, 4)
+        o.collide_planes(self.t, self.f, Lz - 4, Lz - 1)
+        self._communicate("fi")
+        self.t += 1
+        if self.update_fields_ext:
+            self.t_last_update_fields = self.t
+
     def run(self, steps):
         with self.ops.scope():
             if not self.initialized:
                 self._initialize()
+            if self.world > 1 and self.overlap and self.pair_steps and self.local[2] >= 12:
+                for _ in range(int(steps) // 2):
+                    self._do_two_time_steps()
+                steps = int(steps) % 2
             if self.world <= 1 and int(steps) > 0:  # no exchange between the steps: the engine may pair them (lbmhip_stream_collide_steps)
                 self.ops.collide_steps(self.t, self.f, int(steps))
                 self.t += int(steps)

@@ -126,6 +126,13 @@ int lbmhip_stream_collide_planes(lbmhip_domain* domain, uint64_t t, float fx, fl
  * "pair_lag", "pair_blocks_per_cu"; "fused" reads back whether the last call paired its steps.  Environment:
  * LBMHIP_FUSE=0|1. */
 int lbmhip_stream_collide_steps(lbmhip_domain* domain, uint64_t t, uint32_t steps, float fx, float fy, float fz);
+/* Step t on the planes [z_begin, z_end) and step t+1 on the planes [z_begin+2, z_end-2), whose cells depend on nothing
+ * outside [z_begin, z_end) (a slot and its owner are at most one plane apart, kernel.cpp:1332-1345): for the inner planes
+ * of a z-slab, between the exchange of step t-1 and that of step t+1 - the caller steps the planes next to the halos by
+ * lbmhip_stream_collide_planes around the exchange of step t.  One launch with the second step trailing the first where
+ * lbmhip_stream_collide_steps would pair (same conditions, "fused" reads back which), else two launches.  No counterpart
+ * in the reference, which exchanges after every single launch (lbm.cpp:1411-1459). */
+int lbmhip_stream_collide_pair_planes(lbmhip_domain* domain, uint64_t t, float fx, float fy, float fz, uint32_t z_begin, uint32_t z_end);
 int lbmhip_update_fields(lbmhip_domain* domain, uint64_t t, float fx, float fy, float fz); /* kernel.cpp:1812-1894 */
 int lbmhip_update_force_field(lbmhip_domain* domain, uint64_t t);                          /* kernel.cpp:1897-1910 */
 int lbmhip_reset_force_field(lbmhip_domain* domain);                                       /* kernel.cpp:1911-1917 */

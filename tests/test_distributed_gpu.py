@@ -75,16 +75,24 @@ def _self_exchange_worker(rank, port, kw, steps, overlap, out_dir):
         import cfd_amd
         kw = dict(kw)
         N = kw.pop("N")
+        tuning = kw.pop("tuning", {})
+        setup = getattr(setups, kw.pop("setup", "channel"))
         lbm = DistributedLBM((N[0], N[1], 2 * N[2]), rank=0, world=2, overlap=overlap, **kw)  # 2 slabs of N[2] planes; this rank is slab 0
         lbm.next = lbm.prev = 0
+        for key, value in tuning.items():
+            cfd_amd.lbm.check(cfd_amd.lib().lbmhip_set_tuning(lbm.ops.dom.h, key.encode(), int(value)))
         with cfd_amd.LBM(N, **kw) as single:
-            setups.channel(single)
+            single.set_tuning("fuse", 0)
+            setup(single)
             lbm.rho[...] = single.rho; lbm.u[...] = single.u; lbm.flags[...] = single.flags
             single.run(steps)
             single.read_from_device()
             lbm.run(steps)
+            import ctypes
+            fused = ctypes.c_int(-1)  # of the last stream_collide call of the run
+            cfd_amd.lbm.check(cfd_amd.lib().lbmhip_get_tuning(lbm.ops.dom.h, b"fused", ctypes.byref(fused)))
             lbm.read_from_device()
-            np.savez(os.path.join(out_dir, "self.npz"), rho=lbm.rho, u=lbm.u, flags=lbm.flags, rho0=single.rho, u0=single.u, flags0=single.flags)
+            np.savez(os.path.join(out_dir, "self.npz"), rho=lbm.rho, u=lbm.u, flags=lbm.flags, rho0=single.rho, u0=single.u, flags0=single.flags, fused=fused.value)
         lbm.close()
     finally:
         dist.destroy_process_group()
@@ -99,6 +107,20 @@ def test_rccl_exchange_with_itself_equals_periodic_lattice(gpu, tmp_path, overla
     assert np.array_equal(got["rho"].view(np.uint32), got["rho0"].view(np.uint32))
     assert np.array_equal(got["u"].view(np.uint32), got["u0"].view(np.uint32))
     assert float(np.abs(got["u"]).max()) > 1e-4
+
+
+@pytest.mark.parametrize("storage,steps", [("FP32", 20), ("FP16S", 21)])
+def test_slab_steps_paired_in_one_launch_equal_periodic_lattice(gpu, tmp_path, storage, steps):
+    """The slab schedule that takes two steps at a time, with the inner planes of both steps in ONE launch (plain D3Q19 SRT has
+    such a kernel; fuse = 1 uses it on this small lattice), over the production RCCL exchange of a rank that is its own neighbour."""
+    kw = dict(N=(256, 32, 40), nu=0.01, Q=19, storage=storage, collision="SRT", features=(), setup="taylor_green", tuning={"fuse": 1, "pair_lag": 3})
+    mp.spawn(_self_exchange_worker, args=(_free_port(), kw, steps, True, str(tmp_path)), nprocs=1, join=True)
+    got = np.load(os.path.join(str(tmp_path), "self.npz"))
+    assert int(got["fused"]) == 1  # the inner planes did run two steps per launch (the odd run ends with a single step)
+    assert np.array_equal(got["flags"], got["flags0"])
+    assert np.array_equal(got["rho"].view(np.uint32), got["rho0"].view(np.uint32))
+    assert np.array_equal(got["u"].view(np.uint32), got["u0"].view(np.uint32))
+    assert float(np.abs(got["u"]).max()) > 1e-3
 
 
 def test_capacity_lattice_1600_fp16s(gpu):

@@ -1,7 +1,7 @@
 """Diagnostic: step rate of lbmhip_stream_collide_steps (two time steps per launch) over its lag and residency cap,
 against one launch per step.  (GPU needed)
 
-usage: python tools/fused_sweep.py [n] [config: tgv|channel] [storage]
+usage: python tools/fused_sweep.py [n] [config: tgv|channel] [storage] [cells collided together in the paired kernel: 1|2]
 """
 import ctypes as C
 import sys
@@ -15,6 +15,7 @@ lib = cfd_amd.lib()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 config = sys.argv[2] if len(sys.argv) > 2 else "tgv"
 storage = sys.argv[3] if len(sys.argv) > 3 else "FP32"
+together = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 if config == "channel":
     kw = dict(N=(n, n, n), nu=0.01, features=("VOLUME_FORCE", "SUBGRID"), f=(2e-4, 0.0, 0.0), collision="TRT", storage=storage)
 else:
@@ -46,6 +47,7 @@ for _ in range(20):
         break
 print("%s %s %d^3 one launch per step: %.3f ms/step %7.0f MLUPs/s %.1f %% of 8 TB/s" % ((config, storage, n) + rate(40)), flush=True)
 lbm.set_tuning("fuse", 1)
+lbm.set_tuning("pair_cells_together", together)
 for cap in (0, 6, 4, 3):
     for lag in (3, 4, 5, 6, 7, 8):
         lbm.set_tuning("pair_lag", lag); lbm.set_tuning("pair_blocks_per_cu", cap)
