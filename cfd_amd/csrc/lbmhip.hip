@@ -433,6 +433,7 @@ int lbmhip_ddf_stride(const lbmhip_domain* d, uint64_t* elements) {
 	return 0;
 }
 
+static int pairs_steps(const lbmhip_domain* d);
 int lbmhip_set_tuning(lbmhip_domain* d, const char* key, int value) {
 	NEED(d && key, "null argument");
 	if (!strcmp(key, "cells_per_thread")) { NEED(value == 0 || value == 1 || value == 2 || value == 4, "cells_per_thread must be 0 (auto), 1, 2 or 4"); d->cells_per_thread = value; return 0; }
@@ -459,6 +460,7 @@ int lbmhip_get_tuning(lbmhip_domain* d, const char* key, int* value) {
 	if (!strcmp(key, "fused")) { *value = d->pair_used; return 0; } // the last lbmhip_stream_collide_steps call ran two steps per launch
 	if (!strcmp(key, "pair_lag")) { *value = d->pair_used ? d->pair_used_lag : d->pair_lag; return 0; }
 	if (!strcmp(key, "pair_cells_together")) { *value = d->pair_cells_together; return 0; }
+	if (!strcmp(key, "pairs_steps")) { *value = pairs_steps(d); return 0; } // would two steps of this domain share a launch (whole lattice, or the inner planes of a z-slab)?
 	if (!strcmp(key, "pair_blocks_per_cu")) { *value = d->pair_used ? d->pair_used_blocks_per_cu : d->pair_blocks_per_cu; return 0; }
 	return fail("unknown tuning key '%s'", key);
 }
@@ -703,6 +705,13 @@ static bool pair_plan(const lbmhip_domain* d, pair_launch_fn* fn, uint32_t* lag,
 	if (d->fuse < 0 && ((uint64_t)(*lag+4u)*plane_bytes > kPairWindowBytes || (uint64_t)d->cfg.Nx*d->cfg.Ny < 512ull*512ull || lanes_per_row%256u != 0u ||
 	                    d->cfg.velocity_set != 19u || d->cfg.collision != LBMHIP_SRT || d->cfg.features != 0u)) return false;
 	return true;
+}
+static int pairs_steps(const lbmhip_domain* d) {
+	lbm::pair_launch_fn fn = nullptr;
+	uint32_t lag = 0u, xchunks = 1u, block = 256u;
+	int blocks_per_cu = 0;
+	if (!pair_plan(d, &fn, &lag, &blocks_per_cu, &xchunks, &block)) return 0;
+	return d->cfg.Dz == 1u || d->cfg.Nz >= lag+10u; // a slab pairs its planes 2 .. Nz-3
 }
 static int launch_collide_pair_steps(lbmhip_domain* d, pair_launch_fn fn, uint64_t t, float fx, float fy, float fz, uint32_t lag, int blocks_per_cu, uint32_t xchunks, uint32_t block,
                                      uint32_t first1, uint32_t count1, uint32_t first2, uint32_t count2) {

@@ -40,6 +40,7 @@ class SlabOps:
     def download(self, names): raise NotImplementedError
     def initialize(self): raise NotImplementedError
     def collide_planes(self, t, f, z0, z1): raise NotImplementedError
+    def pairs_steps(self): return True  # does collide_pair_planes gain anything over two collide_planes calls? (decides the schedule of run())
     def collide_pair_planes(self, t, f, z0, z1):  # step t on [z0, z1) and step t+1 on [z0+2, z1-2), which depends on nothing else
         self.collide_planes(t, f, z0, z1)
         self.collide_planes(t + 1, f, z0 + 2, z1 - 2)
@@ -120,6 +121,11 @@ class HipSlabOps(SlabOps):
 
     def collide_planes(self, t, f, z0, z1):
         L.check(self.lib.lbmhip_stream_collide_planes(self.dom.h, C.c_uint64(t), C.c_float(f[0]), C.c_float(f[1]), C.c_float(f[2]), int(z0), int(z1)))
+
+    def pairs_steps(self):
+        v = C.c_int(0)
+        L.check(self.lib.lbmhip_get_tuning(self.dom.h, b"pairs_steps", C.byref(v)))
+        return bool(v.value)
 
     def collide_pair_planes(self, t, f, z0, z1):
         L.check(self.lib.lbmhip_stream_collide_pair_planes(self.dom.h, C.c_uint64(t), C.c_float(f[0]), C.c_float(f[1]), C.c_float(f[2]), int(z0), int(z1)))
@@ -349,7 +355,8 @@ class DistributedLBM:
         with self.ops.scope():
             if not self.initialized:
                 self._initialize()
-            if self.world > 1 and self.overlap and self.pair_steps and self.local[2] >= 12:
+            # two steps at a time where the engine then runs the inner planes of both in one launch; otherwise every step keeps its exchange hidden
+            if self.world > 1 and self.overlap and self.pair_steps and self.local[2] >= 12 and int(steps) >= 2 and self.ops.pairs_steps():
                 for _ in range(int(steps) // 2):
                     self._do_two_time_steps()
                 steps = int(steps) % 2

@@ -130,7 +130,8 @@ int lbmhip_stream_collide_steps(lbmhip_domain* domain, uint64_t t, uint32_t step
  * outside [z_begin, z_end) (a slot and its owner are at most one plane apart, kernel.cpp:1332-1345): for the inner planes
  * of a z-slab, between the exchange of step t-1 and that of step t+1 - the caller steps the planes next to the halos by
  * lbmhip_stream_collide_planes around the exchange of step t.  One launch with the second step trailing the first where
- * lbmhip_stream_collide_steps would pair (same conditions, "fused" reads back which), else two launches.  No counterpart
+ * lbmhip_stream_collide_steps would pair (same conditions; lbmhip_get_tuning "pairs_steps" tells beforehand, "fused"
+ * afterwards), else two launches.  No counterpart
  * in the reference, which exchanges after every single launch (lbm.cpp:1411-1459). */
 int lbmhip_stream_collide_pair_planes(lbmhip_domain* domain, uint64_t t, float fx, float fy, float fz, uint32_t z_begin, uint32_t z_end);
 int lbmhip_update_fields(lbmhip_domain* domain, uint64_t t, float fx, float fy, float fz); /* kernel.cpp:1812-1894 */
