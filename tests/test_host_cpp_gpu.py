@@ -230,6 +230,9 @@ def test_cpp_slab_runner_over_rccl(gpu, storage):
     its own z-neighbour the overlapped exchange must reproduce the periodic lattice bit for bit."""
     out = run_example("slab_rccl", timeout=200, env=dict(LBM_SLAB_SELF="1", LBM_SLAB_N="128", LBM_SLAB_STEPS="60", LBM_SLAB_STORAGE=storage))
     assert "halo exchange over RCCL, overlapped" in out and "bit-identical" in out, out
+    # the same with the steps taken two at a time (automatic only from 512 x 512 planes on; forced here), an odd number of them
+    out = run_example("slab_rccl", timeout=200, env=dict(LBM_SLAB_SELF="1", LBM_SLAB_N="128", LBM_SLAB_STEPS="61", LBM_SLAB_STORAGE=storage, LBMHIP_FUSE="1"))
+    assert "steps two at a time" in out and "bit-identical" in out, out
 
 
 def test_export_files_equal_the_reference_format_fixture(gpu, tmp_path):
