@@ -676,11 +676,11 @@ int lbmhip_stream_collide(lbmhip_domain* d, uint64_t t, float fx, float fy, floa
 // that lie between the two steps (lag + 4 of them) must fit the Infinity Cache with room to spare, else the second step
 // reads from HBM like a launch of its own and only the waiting is left.  lag = 2 + the planes the resident workgroups
 // cover, rounded up: the second step then asks for planes whose workgroups have left.  Measured at 512^3
-// D3Q19 FP32 (20 MB planes, tools/fused_sweep.py): no residency cap and lag 4 (77.8 % of 8 TB/s against 68.3 % with a launch
-// per step; lag 3: 70 %, lag 5: 75.5 %, lag 8: 66 %).
+// D3Q19 FP32 (20 MB planes, tools/fused_sweep.py): no residency cap and lag 4 (79.8 % of 8 TB/s against 68.4 % with a launch
+// per step; lag 3: 70 %, lag 5: 77 %, lag 8: 65 %).
 // Automatic mode (fuse = -1) pairs only where it was measured to pay (tools/fused_sweep.py, MI355X): plain D3Q19 SRT on
-// planes of at least 512 x 512 cells made of whole 256-lane chunks - 512^3 FP32 40 700 against 35 700 MLUPs/s (77.8 against
-// 68.3 % of 8 TB/s), FP16S 74 900 against 67 200 (72.1 against 64.6 %).  Smaller planes are a fraction of what is resident on
+// planes of at least 512 x 512 cells made of whole 256-lane chunks - 512^3 FP32 41 400 against 35 700 MLUPs/s (79.2 against
+// 68.3 % of 8 TB/s), FP16S 75 200 against 67 200 (72.5 against 64.6 %).  Smaller planes are a fraction of what is resident on
 // the chip, the lag in planes grows and the best residency cap changes (256^3: 73 against 69 % with at most 6 workgroups
 // per CU, 67 % without a cap; 384^3, whose rows end in a half-empty chunk: 63 against 65 %); the TRT + subgrid channel
 // kernel (132 registers, 3 workgroups per CU) loses 5 %.  fuse = 1 pairs whenever it can.
