@@ -489,16 +489,15 @@ __global__ __launch_bounds__(256, (P == 2 && V == 2 ? 3 : 1)) void k_collide_wid
 }
 
 // ---------------------------------------------------------------------------------------------- two time steps in one launch
-// k_collide_pair runs step t and step t+1 of a lattice that is periodic in z (no halo) in ONE launch, step t+1 trailing
-// step t by a few planes, so that step t+1 finds the DDFs step t wrote in the 256 MiB Infinity Cache instead of in HBM
-// (the reference launches one kernel per step, lbm.cpp:1411-1459; the result is the same bits, since every cell still
-// sees exactly the values the previous step left).
+// k_collide_pair runs step t and step t+1 in ONE launch - of a whole lattice that is periodic in z, or of the inner
+// planes of a z-slab between two halo exchanges - step t+1 trailing step t by a few planes, so that step t+1 finds the
+// DDFs step t wrote in the 256 MiB Infinity Cache instead of in HBM (the reference launches one kernel per step,
+// lbm.cpp:1411-1459; the result is the same bits, since every cell still sees exactly the values the previous step left).
 //   Order of work (blockIdx.y = plane task, dispatched in ascending order), for the whole periodic lattice: step t on
-//   planes 0..lag+1, then alternately step t+1 on plane p and step t on plane p+lag, at the end step t+1 on the planes next
-//   to the periodic seam (Nz-lag .. Nz-1, 0, 1).  PairArgs describes the general form (two plane ranges), which also
-//   covers the inner planes of a z-slab between two halo exchanges.  A workgroup works on one row chunk of one step: with both steps' rows in one workgroup the
-//   second step's loads would queue behind the drain of the first step's stores (measured: 67 % of 8 TB/s against 78 %
-//   with nothing waiting at all).
+//   planes 0..lag+1, then alternately step t+1 on plane p and step t on plane p+lag, at the end step t+1 on the planes
+//   next to the periodic seam (Nz-lag .. Nz-1, 0, 1).  PairArgs describes the general form (two plane ranges).  A
+//   workgroup works on one row chunk of one step: with both steps' rows in one workgroup the second step's loads would
+//   queue behind the drain of the first step's stores (measured: 67 % of 8 TB/s against 78 % with nothing waiting at all).
 //   Dependence: a cell of step t+1 in plane p touches slots in planes p-1..p+1, whose step-t owners sit in planes p-2..p+2
 //   (esoteric-pull: a slot belongs to the cell at its place or to the cell one step against c_i, kernel.cpp:1332-1345).
 //   Every step-t workgroup counts itself done (a counter per plane and shard; the last arriver of a shard reports to the
@@ -507,7 +506,8 @@ __global__ __launch_bounds__(256, (P == 2 && V == 2 ? 3 : 1)) void k_collide_wid
 //   The wait is bounded: when it runs out the workgroup sets *error and goes on (the host then reports the failure).
 //   Visibility between workgroups of the launch (per-XCD L2s are not coherent, a CU's L1 is never refreshed): step t
 //   stores its DDFs written through at agent scope, drains them (s_waitcnt vmcnt(0) in every wave, then a workgroup
-//   barrier) before one lane counts the workgroup done with an agent-scope atomic; step t+1 polls with agent-scope loads,
+//   barrier) before one lane counts the workgroup done with an agent-scope atomic; step t+1 polls with agent-scope loads
+//   (wave 0, with growing pauses: most workgroups of an XCD that is ahead find the XCD that is behind unfinished),
 //   passes a workgroup barrier and loads its DDFs at agent scope.  Step t+1 stores plainly: the next launch reads that.
 //   Step t never reads a byte written in this launch (it runs ahead of step t+1 by more than the two planes step t+1
 //   writes beyond its own), so its loads are plain.

@@ -1,7 +1,7 @@
 """Diagnostic: step rate of lbmhip_stream_collide_steps (two time steps per launch) over its lag and residency cap,
 against one launch per step.  (GPU needed)
 
-usage: python tools/fused_sweep.py [n] [config: tgv|channel] [storage] [cells collided together in the paired kernel: 1|2]
+usage: [SWEEP_CAPS=0,6,4,3] [SWEEP_LAGS=3,4,5,6,7,8] python tools/fused_sweep.py [n] [config: tgv|channel] [storage] [cells collided together in the paired kernel: 1|2]
 """
 import ctypes as C
 import sys
@@ -48,8 +48,11 @@ for _ in range(20):
 print("%s %s %d^3 one launch per step: %.3f ms/step %7.0f MLUPs/s %.1f %% of 8 TB/s" % ((config, storage, n) + rate(40)), flush=True)
 lbm.set_tuning("fuse", 1)
 lbm.set_tuning("pair_cells_together", together)
-for cap in (0, 6, 4, 3):
-    for lag in (3, 4, 5, 6, 7, 8):
+import os
+caps = [int(v) for v in os.environ.get("SWEEP_CAPS", "0,6,4,3").split(",")]
+lags = [int(v) for v in os.environ.get("SWEEP_LAGS", "3,4,5,6,7,8").split(",")]
+for cap in caps:
+    for lag in lags:
         lbm.set_tuning("pair_lag", lag); lbm.set_tuning("pair_blocks_per_cu", cap)
         print("%s %s %d^3 two steps per launch, lag %d, blocks/CU<=%d: %.3f ms/step %7.0f MLUPs/s %.1f %% of 8 TB/s" % ((config, storage, n, lag, cap) + rate(40)), flush=True)
 lbm.close()
