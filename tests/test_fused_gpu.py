@@ -99,3 +99,34 @@ def test_large_planes_pair_only_on_request(gpu):
         assert fused_flag(a) == 1
     finally:
         a.close()
+
+
+def test_pair_planes_entry_point(gpu):
+    """lbmhip_stream_collide_pair_planes(t, [z0, z1)) = step t on [z0, z1) followed by step t+1 on [z0+2, z1-2), whether it runs as one
+    launch or as two; plane ranges that reach into a halo are refused."""
+    L = cfd_amd.lib()
+    zero = C.c_float(0.0)
+    kw = dict(N=(128, 32, 40), nu=0.02)
+    got = {}
+    for name, fuse in (("one launch", 1), ("two launches", 0), ("by hand", 0)):
+        with cfd_amd.LBM(**kw) as lbm:
+            lbm.set_tuning("fuse", fuse); lbm.set_tuning("pair_lag", 3)
+            setups.taylor_green(lbm)
+            lbm.initialize()
+            h = lbm.domains[0].h
+            if name == "by hand":
+                cfd_amd.lbm.check(L.lbmhip_stream_collide_planes(h, C.c_uint64(0), zero, zero, zero, 4, 36))
+                cfd_amd.lbm.check(L.lbmhip_stream_collide_planes(h, C.c_uint64(1), zero, zero, zero, 6, 34))
+            else:
+                cfd_amd.lbm.check(L.lbmhip_stream_collide_pair_planes(h, C.c_uint64(0), zero, zero, zero, 4, 36))
+                assert fused_flag(lbm) == fuse
+            got[name] = bits(lbm.domains[0].download_fi()).copy()
+    assert np.array_equal(got["one launch"], got["by hand"]) and np.array_equal(got["two launches"], got["by hand"])
+    with cfd_amd.LBM(N=(64, 32, 48), nu=0.02, D=(1, 1, 2), devices=[0, 0]) as lbm:
+        setups.taylor_green(lbm)
+        lbm.initialize()
+        h = lbm.domains[0].h
+        assert L.lbmhip_stream_collide_pair_planes(h, C.c_uint64(0), zero, zero, zero, 0, 20) != 0
+        assert b"halo plane" in L.lbmhip_last_error()
+        assert L.lbmhip_stream_collide_pair_planes(h, C.c_uint64(0), zero, zero, zero, 30, 20) != 0
+        cfd_amd.lbm.check(L.lbmhip_stream_collide_pair_planes(h, C.c_uint64(0), zero, zero, zero, 2, 24))  # the inner planes of a slab of 26
