@@ -136,6 +136,7 @@ uint LBM_Domain::get_velocity_set() const { return velocity_set; }
 void LBM_Domain::enqueue_initialize() { check(lbmhip_initialize(handle)); }
 void LBM_Domain::enqueue_stream_collide() { check(lbmhip_stream_collide(handle, t, fx, fy, fz)); }
 void LBM_Domain::enqueue_stream_collide_steps(const uint steps) { check(lbmhip_stream_collide_steps(handle, t, steps, fx, fy, fz)); }
+void LBM_Domain::enqueue_stream_collide_pair_planes(const uint z0, const uint z1) { check(lbmhip_stream_collide_pair_planes(handle, t, fx, fy, fz, z0, z1)); }
 void LBM_Domain::enqueue_stream_collide_planes(const uint z0, const uint z1) { check(lbmhip_stream_collide_planes(handle, t, fx, fy, fz, z0, z1)); }
 void LBM_Domain::enqueue_update_fields() { // lbm.cpp:238-246
 	if (lbm_features()&LBMHIP_UPDATE_FIELDS) return;
@@ -340,6 +341,30 @@ void LBM::do_time_step() { // lbm.cpp:1411-1459, without the per-step host synch
 	for (LBM_Domain* d : lbm_domain) d->increment_time_step();
 }
 
+// z-slabs whose library runs the inner planes of two steps in one launch
+bool LBM::pairs_slab_steps() const {
+	if (!(Dx == 1u && Dy == 1u && Dz > 1u && lbm_domain[0]->get_Nz() >= 12u)) return false;
+	for (const LBM_Domain* d : lbm_domain) { int v = 0; check(lbmhip_get_tuning(d->handle, "pairs_steps", &v)); if (!v) return false; }
+	return true;
+}
+// Two steps of z-slabs: step t next to the halos and its exchange beside ONE launch per domain that runs step t on the
+// inner planes and step t+1 two planes further in (lbmhip_stream_collide_pair_planes), then step t+1 on the six planes near
+// the halos and its exchange.  A cell of step t+1 in plane p depends on step t in the planes p-2 .. p+2 only: same bits as
+// two calls of do_time_step.
+void LBM::do_two_time_steps() {
+	const uint Lz = lbm_domain[0]->get_Nz();
+	for (LBM_Domain* d : lbm_domain) { d->enqueue_stream_collide_planes(1u, 2u); d->enqueue_stream_collide_planes(Lz-2u, Lz-1u); }
+	for (LBM_Domain* d : lbm_domain) check(lbmhip_comm_begin(d->handle));
+	communicate(LBMHIP_HALO_FI);
+	for (LBM_Domain* d : lbm_domain) check(lbmhip_comm_end(d->handle));
+	for (LBM_Domain* d : lbm_domain) d->enqueue_stream_collide_pair_planes(2u, Lz-2u);
+	for (LBM_Domain* d : lbm_domain) check(lbmhip_comm_join(d->handle));
+	for (LBM_Domain* d : lbm_domain) d->increment_time_step();
+	for (LBM_Domain* d : lbm_domain) { d->enqueue_stream_collide_planes(1u, 4u); d->enqueue_stream_collide_planes(Lz-4u, Lz-1u); }
+	communicate(LBMHIP_HALO_FI);
+	for (LBM_Domain* d : lbm_domain) d->increment_time_step();
+}
+
 void LBM::run(const ulong steps, const ulong total_steps) { // lbm.cpp:1461-1489
 	info.append(steps, total_steps, get_t());
 	if (!initialized) initialize();
@@ -352,6 +377,10 @@ void LBM::run(const ulong steps, const ulong total_steps) { // lbm.cpp:1461-1489
 		if (get_D() == 1u) { // no exchange between the steps: the library may run them two per launch (lbmhip_stream_collide_steps)
 			lbm_domain[0]->enqueue_stream_collide_steps((uint)n);
 			lbm_domain[0]->increment_time_step((uint)n);
+		} else if (n >= 2ull && pairs_slab_steps()) {
+			ulong k = 0ull;
+			for (; k+1ull < n; k += 2ull) do_two_time_steps();
+			for (; k < n; k++) do_time_step();
 		} else for (ulong k = 0ull; k < n; k++) do_time_step();
 		for (LBM_Domain* d : lbm_domain) d->finish_queue();
 		const double dt = clock.stop()/(double)n;

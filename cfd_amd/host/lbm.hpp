@@ -78,6 +78,7 @@ public:
 	void enqueue_stream_collide();
 	void enqueue_stream_collide_planes(const uint z0, const uint z1);
 	void enqueue_stream_collide_steps(const uint steps); // `steps` steps with nothing in between (single-domain lattices)
+	void enqueue_stream_collide_pair_planes(const uint z0, const uint z1); // step t on [z0, z1) and step t+1 on [z0+2, z1-2)
 	void enqueue_update_fields();
 	void enqueue_update_force_field();
 	void enqueue_update_moving_boundaries();
@@ -107,6 +108,8 @@ class LBM {
 	void sanity_checks_initialization();
 	void initialize();
 	void do_time_step();
+	void do_two_time_steps(); // z-slabs: two steps with the inner planes of both in one launch per domain
+	bool pairs_slab_steps() const;
 	void communicate(const int what);
 public:
 	// stitches the per-domain host buffers into one global array (Memory_Container, lbm.hpp:239-408)

@@ -377,9 +377,54 @@ class LBM:
         if self.update_fields_ext:
             self.t_last_update_fields = self.t
 
+    def _pairs_slab_steps(self):
+        """z-slabs whose engine runs the inner planes of two steps in one launch (lbmhip_get_tuning "pairs_steps")."""
+        if not (self.overlap and self.D[0] == 1 and self.D[1] == 1 and self.D[2] > 1 and self.local[2] >= 12):
+            return False
+        v = C.c_int(0)
+        for dom in self.domains:
+            check(self._L.lbmhip_get_tuning(dom.h, b"pairs_steps", C.byref(v)))
+            if not v.value:
+                return False
+        return True
+
+    def _do_two_time_steps(self):
+        """Two steps of z-slabs with the inner planes of both in one launch per domain (lbmhip_stream_collide_pair_planes): step t next to
+        the halos and its exchange beside that launch, then step t+1 on the six planes near the halos and its exchange.  Same bits as
+        two calls of do_time_step (a cell of step t+1 in plane p depends on step t in the planes p-2 .. p+2 only)."""
+        L = self._L
+        Lz = self.local[2]
+        fx, fy, fz = C.c_float(self.fx), C.c_float(self.fy), C.c_float(self.fz)
+        t = C.c_uint64(self.t)
+        for dom in self.domains:
+            check(L.lbmhip_stream_collide_planes(dom.h, t, fx, fy, fz, 1, 2))
+            check(L.lbmhip_stream_collide_planes(dom.h, t, fx, fy, fz, Lz - 2, Lz - 1))
+        for dom in self.domains:
+            check(L.lbmhip_comm_begin(dom.h))
+        self._communicate(HALO_FI)
+        for dom in self.domains:
+            check(L.lbmhip_comm_end(dom.h))
+        for dom in self.domains:
+            check(L.lbmhip_stream_collide_pair_planes(dom.h, t, fx, fy, fz, 2, Lz - 2))  # step t on 2 .. Lz-3, step t+1 on 4 .. Lz-5
+        for dom in self.domains:
+            check(L.lbmhip_comm_join(dom.h))
+        self.t += 1
+        t = C.c_uint64(self.t)
+        for dom in self.domains:
+            check(L.lbmhip_stream_collide_planes(dom.h, t, fx, fy, fz, 1, 4))
+            check(L.lbmhip_stream_collide_planes(dom.h, t, fx, fy, fz, Lz - 4, Lz - 1))
+        self._communicate(HALO_FI)
+        self.t += 1
+        if self.update_fields_ext:
+            self.t_last_update_fields = self.t
+
     def run(self, steps):
         if not self.initialized:
             self.initialize()
+        if int(steps) >= 2 and self._pairs_slab_steps():
+            for _ in range(int(steps) // 2):
+                self._do_two_time_steps()
+            steps = int(steps) % 2
         if len(self.domains) == 1 and int(steps) > 0:  # no exchange between the steps: the library may run them two per launch
             check(self._L.lbmhip_stream_collide_steps(self.domains[0].h, C.c_uint64(self.t), C.c_uint32(int(steps)), C.c_float(self.fx), C.c_float(self.fy), C.c_float(self.fz)))
             self.t += int(steps)

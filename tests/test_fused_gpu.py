@@ -130,3 +130,22 @@ def test_pair_planes_entry_point(gpu):
         assert b"halo plane" in L.lbmhip_last_error()
         assert L.lbmhip_stream_collide_pair_planes(h, C.c_uint64(0), zero, zero, zero, 30, 20) != 0
         cfd_amd.lbm.check(L.lbmhip_stream_collide_pair_planes(h, C.c_uint64(0), zero, zero, zero, 2, 24))  # the inner planes of a slab of 26
+
+
+def test_slabs_of_one_process_pair_their_steps(gpu):
+    """cfd_amd.LBM with z-slabs (two and three domains on the one GPU): run() takes the steps two at a time, the inner planes of both in
+    one launch per domain, and gives the oracle's multi-domain bits."""
+    for D, storage in (((1, 1, 2), "FP32"), ((1, 1, 3), "FP16S")):
+        kw = dict(N=(128, 32, 40 * D[2]), nu=0.02, D=D, storage=storage)
+        a = cfd_amd.LBM(devices=[0] * D[2], **kw); b = H.OracleLBM(**kw)
+        try:
+            a.set_tuning("fuse", 1); a.set_tuning("pair_lag", 3)
+            setups.taylor_green(a); setups.taylor_green(b)
+            a.run(9); b.run(9)
+            assert a._pairs_slab_steps() and fused_flag(a) == 1
+            for da, db in zip(a.domains, b.domains):
+                assert np.array_equal(bits(da.download_fi()), bits(db.fi)), (D, storage)
+            a.read_from_device(); b.read_from_device()
+            assert np.array_equal(bits(a.rho), bits(b.rho)) and np.array_equal(bits(a.u), bits(b.u))
+        finally:
+            a.close()

@@ -49,6 +49,16 @@ def test_taylor_green_example_matches_python_mirror(gpu):
     assert re.search(r"Average MLUPs/s = \d+\n", status) and "Kinematic Viscosity = 1.00000000E-2\n" in status and "Volume Force" not in status
 
 
+def test_slabs_in_one_process_take_two_steps_at_a_time(gpu):
+    """LBM::run on z-slabs (two domains on the one GPU, lbmhip_halo_exchange_local): with the inner planes of two steps in one launch per
+    domain (LBMHIP_FUSE=1 forces that on this small lattice) the velocity field has the bits of the undivided lattice stepped one launch at a time."""
+    checksum = lambda out: [l for l in out.splitlines() if l.startswith("u checksum ")][0]
+    whole = checksum(run_example("taylor_green", env={"LBM_EXAMPLE_STEPS": "51", "LBMHIP_FUSE": "0"}))
+    slabs = checksum(run_example("taylor_green", env={"LBM_EXAMPLE_STEPS": "51", "LBMHIP_FUSE": "1", "LBM_EXAMPLE_DOMAINS": "1x1x2"}))
+    paired_whole = checksum(run_example("taylor_green", env={"LBM_EXAMPLE_STEPS": "51", "LBMHIP_FUSE": "1"}))
+    assert whole == slabs == paired_whole, (whole, slabs, paired_whole)
+
+
 def test_cavity_example_runs(gpu):
     out = run_example("cavity")
     value = float([l for l in out.splitlines() if re.fullmatch(r"-?[0-9.eE+-]+", l.strip())][0])
