@@ -149,3 +149,21 @@ def test_slabs_of_one_process_pair_their_steps(gpu):
             assert np.array_equal(bits(a.rho), bits(b.rho)) and np.array_equal(bits(a.u), bits(b.u))
         finally:
             a.close()
+
+
+@pytest.mark.parametrize("storage", ["FP32", "FP16S"])
+def test_headline_lattice_paired_equals_single_launches(gpu, storage):
+    """512^3, the lattice of the headline figure, where pairing is automatic: 200 steps with two steps per launch (100 launches of
+    a million workgroups each) leave the bits of 200 single launches in every DDF stream."""
+    import zlib
+    crcs = {}
+    for fuse in (-1, 0):
+        with cfd_amd.LBM(N=(512, 512, 512), nu=0.01, storage=storage) as lbm:
+            lbm.set_tuning("fuse", fuse); lbm.set_tuning("autotune", 0)
+            setups.taylor_green(lbm)
+            lbm.run(200)
+            assert fused_flag(lbm) == (1 if fuse else 0)
+            fi = lbm.domains[0].download_fi()
+            n = 512 ** 3
+            crcs[fuse] = [zlib.crc32(fi[i * n:(i + 1) * n]) for i in range(19)]
+    assert crcs[-1] == crcs[0]
