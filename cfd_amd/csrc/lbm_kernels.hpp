@@ -116,7 +116,7 @@ __device__ __forceinline__ void collide_row(const Args& a, const uint32_t chunk,
 		// D3Q19) are 256 contiguous, aligned bytes per wave: lanes 0..15 collect four neighbouring lanes' values each
 		// (ds_bpermute) and store them as 16 bytes.  Waves with lanes past the row end keep the 4-byte stores.
 		const uint32_t lane = threadIdx.x&63u;
-		if (__ballot(true) == ~0ull) {
+		if (__ballot(true) == ~0ull && ((a.Nx|(uint32_t)a.S)&3u) == 0u) { // rows and streams that start on 16-byte boundaries
 			const uint32_t from = (lane&15u)*16u, wave_xb = fresh((x-lane)*RB+lane*16u);
 			typedef uint32_t quad __attribute__((ext_vector_type(4)));
 			auto store16 = [&](raw* const base, const raw value) {
@@ -134,7 +134,7 @@ __device__ __forceinline__ void collide_row(const Args& a, const uint32_t chunk,
 				constexpr int i = I, cx = dir<Q>(i,0);
 				store16(pa[i], r[i]);
 				if constexpr (cx == 0) store16(pa[i+1], r[i+1]);
-				else st_ddf<MEM>(pa[i+1], cx > 0 ? sxpb : sxmb, r[i+1]); // one column to the side: 4 bytes per lane (its 15 aligned groups as 16 bytes and four single cells: 78.3 against 79.8 % of 8 TB/s)
+				else st_ddf<MEM>(pa[i+1], cx > 0 ? sxpb : sxmb, r[i+1]); // one column to the side: 4 bytes per lane.  Measured and slower (79.8 % of 8 TB/s as it is): its 15 aligned groups of four as 16 bytes + four single cells 78.3 %; aligned pairs as 8 bytes from every second lane + two single cells 76.3 %
 			});
 			return;
 		}
