@@ -215,7 +215,14 @@ int lbmhip_timer_stop(lbmhip_domain* domain, float* milliseconds); /* waits for 
  * per compute unit, counted in 256-lane workgroups), "autotune" (1 = default: while all these knobs are on auto, the first full-lattice
  * stream_collide launches of a lattice of at least 2^21 cells each try one launch geometry between two events (three
  * times each) and the one with the best median is kept; every geometry computes the same bits.  0 = fixed defaults; the environment variable
- * LBMHIP_AUTOTUNE=0 has the same effect for every domain created afterwards) */
+ * LBMHIP_AUTOTUNE=0 has the same effect for every domain created afterwards).
+ * Two steps per launch (lbmhip_stream_collide_steps, lbmhip_stream_collide_pair_planes): "fuse" (-1 = automatic: plain D3Q19
+ * SRT on planes of at least 512 x 512 cells that fit the Infinity Cache lag+4 at a time; 0 = never; 1 = whenever a compiled
+ * instance exists; LBMHIP_FUSE=0|1 sets it for every domain created afterwards), "pair_lag" (0 = automatic, 3..64: planes the
+ * second step trails the first by), "pair_blocks_per_cu" (-1 = automatic, 0 = no limit), "pair_cells_together" (16-bit DDFs:
+ * 1 or 2).  Read-only keys of lbmhip_get_tuning: "tuned" (the search has finished), "jit" (the last launch ran a kernel
+ * compiled at run time), "pairs_steps" (two steps of this domain would share a launch), "fused" (the last
+ * lbmhip_stream_collide_steps / lbmhip_stream_collide_pair_planes call did pair its steps). */
 int lbmhip_set_tuning(lbmhip_domain* domain, const char* key, int value);
 /* Reads back a launch setting ("cells_per_thread", "cells_together", "blocks_per_cu", "block", "autotune"), "tuned" (1 once
  * the geometry search has finished; the launch settings then report its choice) or "jit" (1 when the last stream_collide
