@@ -32,7 +32,21 @@ hipError_t launch_collide_pair(const Args& a, const PairArgs& p, dim3 grid, dim3
 	hipLaunchKernelGGL((k_collide_pair<Q, ST, COLL, FEAT, V, P>), grid, block, lds_bytes, stream, a, p);
 	return hipGetLastError();
 }
-pair_launch_fn select_collide_pair(int Q, int ST, int COLL, int FEAT, int V, int P); // V = 1 (FP32 DDFs) or 2 (16-bit DDFs)
+// the same two steps band by band on each XCD (k_collide_band) and the launch that finishes them (k_collide_seam)
+typedef hipError_t (*band_launch_fn)(const Args&, const BandArgs&, dim3 grid, dim3 block, uint32_t lds_bytes, hipStream_t stream);
+typedef hipError_t (*seam_launch_fn)(const Args&, const SeamArgs&, dim3 grid, dim3 block, uint32_t lds_bytes, hipStream_t stream);
+template <int Q, int ST, int COLL, int FEAT, int V, int P>
+hipError_t launch_collide_band(const Args& a, const BandArgs& p, dim3 grid, dim3 block, uint32_t lds_bytes, hipStream_t stream) {
+	hipLaunchKernelGGL((k_collide_band<Q, ST, COLL, FEAT, V, P>), grid, block, lds_bytes, stream, a, p);
+	return hipGetLastError();
+}
+template <int Q, int ST, int COLL, int FEAT, int V, int P>
+hipError_t launch_collide_seam(const Args& a, const SeamArgs& p, dim3 grid, dim3 block, uint32_t lds_bytes, hipStream_t stream) {
+	hipLaunchKernelGGL((k_collide_seam<Q, ST, COLL, FEAT, V, P>), grid, block, lds_bytes, stream, a, p);
+	return hipGetLastError();
+}
+struct PairKernels { pair_launch_fn pair; band_launch_fn band; seam_launch_fn seam; };
+PairKernels select_collide_pair(int Q, int ST, int COLL, int FEAT, int V, int P); // V = 1 (FP32 DDFs) or 2 (16-bit DDFs); all null without an instance
 
 // FEAT < 0 selects the instance that reads the feature mask at run time; FO = update_fields (always run-time features)
 // V = cells per lane; P = 2 selects the instance that collides two cells at a time in packed arithmetic (V = 2 or 4 only)

@@ -583,6 +583,135 @@ __global__ __launch_bounds__(256, (P == 2 && V == 2 ? 3 : 1)) void k_collide_pai
 	}
 }
 
+// ---------------------------------------------------------------------------------------------- two time steps in one launch, band by band on each XCD
+// k_collide_band is the second form of two steps per launch: step t+1 finds what step t wrote in the L2 of its own XCD (4 MiB)
+// instead of in the Infinity Cache, and what it writes over those lines leaves the L2 once instead of twice.
+//   Which cells depend on which: between two consecutive steps the owner of a DDF slot moves by exactly one c_i (stream i at
+//   place m belongs to cell m at one parity of t and to cell m-c_i at the other, kernel.cpp:1332-1345), so a cell of step t+1
+//   at (x, y, z) needs step t finished on the rows y-1..y+1 of the planes z-1..z+1 and on nothing else.
+//   Order of work: the rows of the lattice are cut into eight blocks, one per XCD (workgroups are dealt to the XCDs round-robin
+//   by their linear index, which blockIdx.x % 8 stands for here), a block into bands of R rows.  An XCD sweeps band after
+//   band along z, step t+1 trailing step t by `lag` planes and shifted down by one row (its rows b0-1..b1-2 need step t on
+//   b0-2..b1-1: the band itself and the two rows above the band swept before), so that the lines between the two steps are a
+//   few hundred KB per plane of the band.  The first and the last row of every block need step t from a neighbouring XCD:
+//   their step t+1 is left to k_collide_seam, a launch of its own behind this one (16 of Ny rows per plane).
+//   Hand-over inside an XCD: step t stores plainly (the lines stay in the XCD's L2, dirty), every wave drains its stores
+//   (s_waitcnt vmcnt(0): acknowledged by the L2), the workgroup passes a barrier and one lane counts it done on the counter
+//   of (XCD it ran on, band, plane) - the XCD is read from the hardware register, not inferred.  Step t+1 polls the counters
+//   of ITS XCD with agent-scope loads, passes a barrier and loads its DDFs past the L1 (sc1: served by the L2, which is the
+//   one copy all CUs of an XCD share; the same order makes workgroup scope coherent when the waves of one workgroup run on
+//   several CUs of an XCD).  Were the workgroups dealt differently, a counter would never fill and nothing stale be read:
+//   the wait is bounded, a wait that runs out raises *error, every other wait sees that and gives up too, and a workgroup
+//   that gives up writes its task to the redo list and computes nothing.  k_collide_seam then runs those tasks (step t is
+//   complete by then and nothing in the launch depends on step t+1), so the lattice is right in every case and only the
+//   time is lost; the host turns the pairing off when it finds *error set.
+struct BandArgs {
+	uint32_t* done;        // [8 XCDs][bands per block][Nz]: step-t workgroups that have finished (zeroed before the launch)
+	uint32_t* error;       // raised by a wait that ran out (zeroed before the launch)
+	uint32_t* redo_count;  // tasks of step t+1 given up (zeroed before the launch)
+	uint64_t* redo;        // their (z*Ny+y)*xchunks+chunk
+	uint32_t block_rows;   // rows per XCD block
+	uint32_t R, bands;     // rows per band (>= 2: the two rows above a band lie in the band before it), bands per block
+	uint32_t lag;          // >= 2: step t+1 on plane first2+j follows step t on plane first2+j+lag-1
+	uint32_t spin_limit;   // polls before a wait gives up
+	uint32_t first1, count1, first2, count2; // planes of step t and of step t+1 (modulo Nz), as in PairArgs but first2 >= first1+1 suffices
+};
+__device__ __forceinline__ uint32_t xcd_of_this_wave() { uint32_t x; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(x)); return x&7u; }
+template <int Q, int ST, int COLL, int FEAT, int V = 1, int P = 1>
+__global__ __launch_bounds__(256, (P == 2 && V == 2 ? 3 : 1)) void k_collide_band(const Args a, const BandArgs p) {
+	__shared__ uint32_t give_up;
+	const uint32_t Nz = a.Nz, block_of = blockIdx.x&7u, within = blockIdx.x>>3, task = blockIdx.y, band = blockIdx.z; // grid = (8*R*xchunks, count1+count2, bands)
+	const uint32_t bs = block_of*p.block_rows, be = min(bs+p.block_rows, a.Ny); // this block's rows
+	const uint32_t b0 = bs+band*p.R, b1 = min(b0+p.R, be);                        // this band's rows
+	if (bs >= a.Ny || b0 >= be) return;
+	const uint32_t ahead = min(p.count1, p.first2+p.lag-p.first1), both = min(p.count1-ahead, p.count2);
+	uint32_t z, second = 0u;
+	if (task < ahead) z = p.first1+task;
+	else if (task < ahead+2u*both) { const uint32_t k = task-ahead; second = (k&1u)^1u; z = second ? p.first2+k/2u : p.first1+ahead+k/2u; }
+	else if (ahead+both < p.count1) z = p.first1+ahead+both+(task-ahead-2u*both);
+	else { second = 1u; z = p.first2+both+(task-ahead-2u*both); }
+	if (z >= Nz) z -= Nz;
+	const uint32_t chunk = within%a.xchunks, row = within/a.xchunks, xcd = xcd_of_this_wave();
+	if (!second) {
+		const uint32_t y = b0+row;
+		if (y >= b1) return;
+		__builtin_amdgcn_s_setprio(2); // step t is what step t+1 waits for
+		if constexpr (V == 1) collide_row<Q, ST, COLL, FEAT, false>(a, chunk, y, z);
+		else collide_row_wide<Q, ST, COLL, FEAT, V, P>(a, chunk, y, z);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's stores have been acknowledged by the L2
+		__syncthreads();
+		if (threadIdx.x == 0u) __hip_atomic_fetch_add(p.done+((uint64_t)(xcd*p.bands+band)*Nz+z), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	} else {
+		// rows b0-1 .. b1-2; the block's first row and the row above it, and the block's last row, are not this launch's
+		const uint32_t lo = band == 0u ? bs+1u : max(b0-1u, bs+1u), hi = b1 == be ? be-1u : b1-1u;
+		if (b0+row < lo+1u || b0+row-1u >= hi) return;
+		const uint32_t y = b0+row-1u;
+		const uint32_t x = (chunk*blockDim.x+threadIdx.x)*(uint32_t)V;
+		uint32_t early = 0u;
+		if (x < a.Nx) early = ld<uint8_t>(a.flags+((uint64_t)z*a.Ny+y)*a.Nx, x); // flags are never written by a step
+		if (threadIdx.x < 64u) {
+			// lanes 0..2: the band's own counters of the planes z-1..z+1; lanes 3..5: those of the band above (swept before), whose last
+			// two rows the rows b0-1 and b0 need; lane 6: the error word
+			const uint32_t lane = threadIdx.x, prev = lane >= 3u ? 1u : 0u;
+			const uint32_t zz = (z+Nz-1u+(lane < 6u ? lane-3u*prev : 0u))%Nz;
+			const bool asked = lane < 6u && (zz+Nz-p.first1)%Nz < p.count1 && (!prev || (band > 0u && y <= b0)); // planes outside this launch's step t were finished by earlier launches
+			const uint32_t need = (prev ? p.R : b1-b0)*a.xchunks;
+			const uint32_t* const word = lane == 6u ? p.error : p.done+((uint64_t)(xcd*p.bands+(asked && prev ? band-1u : band))*Nz+zz);
+			bool failed = false;
+			for (uint32_t spins = 0u; ; spins++) {
+				uint32_t v = 0u;
+				if (asked || lane == 6u) v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (__ballot(lane == 6u && v != 0u) != 0ull) { failed = true; break; }
+				if (__ballot(asked && v < need) == 0ull) break;
+				if (spins >= p.spin_limit) { if (lane == 0u) __hip_atomic_store(p.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); failed = true; break; }
+				if (spins < 2u) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(127);
+			}
+			if (lane == 0u) {
+				give_up = failed ? 1u : 0u;
+				if (failed) p.redo[__hip_atomic_fetch_add(p.redo_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = ((uint64_t)z*a.Ny+y)*a.xchunks+chunk;
+			}
+		}
+		__syncthreads();
+		if (give_up) return;
+		Args b = a;
+		b.odd = a.odd^1u;
+		if constexpr (V == 1) collide_row<Q, ST, COLL, FEAT, false, MEM_LOAD_COHERENT, true>(b, chunk, y, z, early);
+		else {
+			asm volatile("" :: "v"(early));
+			collide_row_wide<Q, ST, COLL, FEAT, V, P, false, MEM_LOAD_COHERENT>(b, chunk, y, z);
+		}
+	}
+}
+// What k_collide_band leaves of step t+1: the rows at the edges of the XCD blocks (blockIdx.y < count2: plane first2+blockIdx.y,
+// blockIdx.x = row of the list * xchunks + chunk), and the tasks on the redo list (blockIdx.y == count2, the workgroups
+// stride over the list).  `a` is step t+1's (odd flipped by the host).  Plain accesses: a launch of its own.
+struct SeamArgs {
+	uint32_t rows[16], nrows;
+	uint32_t first2, count2;
+	const uint32_t* redo_count;
+	const uint64_t* redo;
+};
+template <int Q, int ST, int COLL, int FEAT, int V = 1, int P = 1>
+__global__ __launch_bounds__(256, (P == 2 && V == 2 ? 3 : 1)) void k_collide_seam(const Args a, const SeamArgs p) {
+	if (blockIdx.y < p.count2) {
+		const uint32_t row = blockIdx.x/a.xchunks, chunk = blockIdx.x%a.xchunks;
+		if (row >= p.nrows) return;
+		uint32_t z = p.first2+blockIdx.y;
+		if (z >= a.Nz) z -= a.Nz;
+		if constexpr (V == 1) collide_row<Q, ST, COLL, FEAT, false>(a, chunk, p.rows[row], z);
+		else collide_row_wide<Q, ST, COLL, FEAT, V, P>(a, chunk, p.rows[row], z);
+	} else {
+		const uint32_t n = *p.redo_count;
+		for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) {
+			const uint64_t e = p.redo[k];
+			const uint32_t chunk = (uint32_t)(e%a.xchunks);
+			const uint64_t zy = e/a.xchunks;
+			if constexpr (V == 1) collide_row<Q, ST, COLL, FEAT, false>(a, chunk, (uint32_t)(zy%a.Ny), (uint32_t)(zy/a.Ny));
+			else collide_row_wide<Q, ST, COLL, FEAT, V, P>(a, chunk, (uint32_t)(zy%a.Ny), (uint32_t)(zy/a.Ny));
+		}
+	}
+}
+
 #ifdef LBM_SMALL_KERNELS // the one-cell-per-thread kernels are compiled once, in lbmhip.hip
 // ---------------------------------------------------------------------------------------------- one-cell-per-thread helpers
 struct Cell { uint32_t x, y, z; uint64_t n; bool valid; };

@@ -54,7 +54,13 @@ struct lbmhip_domain {
 	// two time steps per launch (k_collide_pair): completion counters of the first step's workgroups, then one error word
 	uint32_t* pair_sync; uint64_t pair_sync_words; uint32_t pair_replica_stride;
 	int fuse, pair_lag, pair_blocks_per_cu, pair_cells_together; // fuse: -1 = automatic, 0 = never, 1 = whenever a compiled instance exists; pair_lag 0 = automatic; pair_blocks_per_cu -1 = automatic
-	int pair_used, pair_used_lag, pair_used_blocks_per_cu, pair_unchecked; // what the last lbmhip_stream_collide_steps call ran; launches since the error word was last read
+	int pair_used, pair_used_lag, pair_used_blocks_per_cu, pair_unchecked; // what the last lbmhip_stream_collide_steps call ran (pair_used: 0 = a launch per step, 1 = k_collide_pair, 2 = k_collide_band); launches since the error word was last read
+	// two time steps per launch, band by band on each XCD (k_collide_band): 16 header words (error, redo count), the completion
+	// counters, and the redo list; allocated at the first such launch
+	uint32_t* band_sync; uint64_t band_sync_words; uint64_t* band_redo; uint64_t band_redo_capacity;
+	int band_rows, band_lag, band_blocks_per_cu; // rows per band, lag in planes, residency cap: 0 / 0 / -1 = automatic
+	int band_spin_limit, band_used_rows;
+	int band_unchecked, band_given_up;            // launches since the error word was last read; launches found to have given up waits (their tasks were redone)
 	int compute_units;
 };
 
@@ -274,7 +280,8 @@ int lbmhip_domain_create(const lbmhip_config* c, lbmhip_domain** out) {
 	}
 	e = hipMalloc(&d->partial, kObjectSumBlocks*4u*sizeof(float));
 	d->fuse = -1; d->pair_lag = 0; d->pair_blocks_per_cu = -1; d->pair_cells_together = 1;
-	{ const char* env = getenv("LBMHIP_FUSE"); if (env && (env[0] == '0' || env[0] == '1') && !env[1]) d->fuse = env[0]-'0'; }
+	d->band_rows = 0; d->band_lag = 0; d->band_blocks_per_cu = -1; d->band_spin_limit = -1;
+	{ const char* env = getenv("LBMHIP_FUSE"); if (env && env[0] >= '0' && env[0] <= '2' && !env[1]) d->fuse = env[0]-'0'; }
 	if (e == hipSuccess) e = hipDeviceGetAttribute(&d->compute_units, hipDeviceAttributeMultiprocessorCount, c->device);
 	if (e == hipSuccess && c->Dx == 1u && c->Dy == 1u && c->Nz >= 8u) { // what k_collide_pair needs, whether or not it is ever used (264 KB at 512 planes)
 		d->pair_replica_stride = (c->Nz+63u)/64u*64u+32u; // the replicas start on different cache lines, an odd number of lines apart
@@ -305,6 +312,8 @@ int lbmhip_domain_destroy(lbmhip_domain* d) {
 	for (int k = 0; k < 4; k++) if (d->halo_own[k]) (void)hipFree(d->halo_own[k]);
 	if (d->partial) (void)hipFree(d->partial);
 	if (d->pair_sync) (void)hipFree(d->pair_sync);
+	if (d->band_sync) (void)hipFree(d->band_sync);
+	if (d->band_redo) (void)hipFree(d->band_redo);
 	if (d->mesh) (void)hipFree(d->mesh);
 	if (d->ev_start) (void)hipEventDestroy(d->ev_start);
 	if (d->ev_stop) (void)hipEventDestroy(d->ev_stop);
@@ -338,6 +347,16 @@ int lbmhip_get_stream(lbmhip_domain* d, void** stream) {
 // After the stream has been synchronised: did a wait inside a two-step launch run out?  (It cannot while workgroups are
 // dispatched in grid order; if it ever does, the lattice holds wrong values and the caller must know.)
 static int pair_check(lbmhip_domain* d) {
+	if (d->band_unchecked && d->band_sync) { // k_collide_band: a wait that ran out cost time, not results (its tasks were redone by k_collide_seam)
+		uint32_t flag = 0u;
+		HIP_TRY(hipMemcpy(&flag, d->band_sync, sizeof(flag), hipMemcpyDeviceToHost));
+		d->band_unchecked = 0;
+		if (flag) {
+			d->band_given_up++;
+			if (d->fuse < 0 || d->fuse == 2) d->fuse = 0;
+			fprintf(stderr, "lbmhip: a two-step launch gave up waiting for its first step and finished step by step; two-step launches are now off for this domain\n");
+		}
+	}
 	if (!d->pair_unchecked || !d->pair_sync) return 0;
 	uint32_t flag = 0u;
 	HIP_TRY(hipMemcpy(&flag, d->pair_sync+d->pair_sync_words-16u, sizeof(flag), hipMemcpyDeviceToHost));
@@ -441,7 +460,11 @@ int lbmhip_set_tuning(lbmhip_domain* d, const char* key, int value) {
 	if (!strcmp(key, "blocks_per_cu")) { NEED(value >= -1 && value <= 32, "blocks_per_cu must be -1 (auto), 0 (no limit) or 1..32"); d->blocks_per_cu = value; return 0; }
 	if (!strcmp(key, "block")) { NEED(value == 0 || (value >= 64 && value <= 256 && value%64 == 0), "block must be 0 (auto), 64, 128, 192 or 256"); d->block = value; return 0; }
 	if (!strcmp(key, "autotune")) { NEED(value == 0 || value == 1, "autotune must be 0 or 1"); d->autotune = value; if (!value) { d->tuned = 0; d->tune_launches = 0; d->tune_pending = -1; } return 0; }
-	if (!strcmp(key, "fuse")) { NEED(value >= -1 && value <= 1, "fuse must be -1 (auto), 0 or 1"); d->fuse = value; return 0; }
+	if (!strcmp(key, "fuse")) { NEED(value >= -1 && value <= 2, "fuse must be -1 (auto), 0 (never), 1 (k_collide_pair) or 2 (k_collide_band)"); d->fuse = value; return 0; }
+	if (!strcmp(key, "band_rows")) { NEED(value == 0 || (value >= 2 && value <= 4096), "band_rows must be 0 (auto) or 2..4096"); d->band_rows = value; return 0; }
+	if (!strcmp(key, "band_lag")) { NEED(value == 0 || (value >= 2 && value <= 64), "band_lag must be 0 (auto) or 2..64"); d->band_lag = value; return 0; }
+	if (!strcmp(key, "band_blocks_per_cu")) { NEED(value >= -1 && value <= 32, "band_blocks_per_cu must be -1 (auto), 0 (no limit) or 1..32"); d->band_blocks_per_cu = value; return 0; }
+	if (!strcmp(key, "band_spin_limit")) { NEED(value >= -1, "band_spin_limit must be -1 (default) or a number of polls"); d->band_spin_limit = value; return 0; }
 	if (!strcmp(key, "pair_lag")) { NEED(value == 0 || (value >= 3 && value <= 64), "pair_lag must be 0 (auto) or 3..64"); d->pair_lag = value; return 0; }
 	if (!strcmp(key, "pair_cells_together")) { NEED(value == 1 || value == 2, "pair_cells_together must be 1 or 2"); d->pair_cells_together = value; return 0; }
 	if (!strcmp(key, "pair_blocks_per_cu")) { NEED(value >= -1 && value <= 32, "pair_blocks_per_cu must be -1 (auto), 0 (no limit) or 1..32"); d->pair_blocks_per_cu = value; return 0; }
@@ -457,7 +480,11 @@ int lbmhip_get_tuning(lbmhip_domain* d, const char* key, int* value) {
 	if (!strcmp(key, "tuned")) { *value = d->tuned; return 0; }
 	if (!strcmp(key, "jit")) { *value = d->uses_jit; return 0; }
 	if (!strcmp(key, "fuse")) { *value = d->fuse; return 0; }
-	if (!strcmp(key, "fused")) { *value = d->pair_used; return 0; } // the last lbmhip_stream_collide_steps call ran two steps per launch
+	if (!strcmp(key, "fused")) { *value = d->pair_used; return 0; } // the last lbmhip_stream_collide_steps call ran two steps per launch (1: k_collide_pair, 2: k_collide_band)
+	if (!strcmp(key, "band_rows")) { *value = d->pair_used == 2 ? d->band_used_rows : d->band_rows; return 0; }
+	if (!strcmp(key, "band_lag")) { *value = d->pair_used == 2 ? d->pair_used_lag : d->band_lag; return 0; }
+	if (!strcmp(key, "band_blocks_per_cu")) { *value = d->pair_used == 2 ? d->pair_used_blocks_per_cu : d->band_blocks_per_cu; return 0; }
+	if (!strcmp(key, "band_given_up")) { *value = d->band_given_up; return 0; } // two-step launches whose waits ran out (checked when the stream is synchronised)
 	if (!strcmp(key, "pair_lag")) { *value = d->pair_used ? d->pair_used_lag : d->pair_lag; return 0; }
 	if (!strcmp(key, "pair_cells_together")) { *value = d->pair_cells_together; return 0; }
 	if (!strcmp(key, "pairs_steps")) { *value = pairs_steps(d); return 0; } // would two steps of this domain share a launch (whole lattice, or the inner planes of a z-slab)?
@@ -685,59 +712,124 @@ int lbmhip_stream_collide(lbmhip_domain* d, uint64_t t, float fx, float fy, floa
 // per CU, 67 % without a cap; 384^3, whose rows end in a half-empty chunk: 63 against 65 %); the TRT + subgrid channel
 // kernel (132 registers, 3 workgroups per CU) loses 5 %.  fuse = 1 pairs whenever it can.
 static const uint64_t kPairWindowBytes = 200ull<<20;
-static bool pair_plan(const lbmhip_domain* d, pair_launch_fn* fn, uint32_t* lag, int* blocks_per_cu, uint32_t* xchunks, uint32_t* block) {
+// mode 1: k_collide_pair (step t+1 reads from the Infinity Cache, any placement of the workgroups); mode 2: k_collide_band (from the L2 of
+// the XCD, band by band, + k_collide_seam)
+struct PairPlan { PairKernels k; int mode; uint32_t lag, xchunks, block; int blocks_per_cu; uint32_t block_rows, R, bands; };
+static bool pair_plan(const lbmhip_domain* d, PairPlan* plan) {
 	if (d->fuse == 0 || !d->pair_sync || (d->cfg.features&LBMHIP_UPDATE_FIELDS) || d->cfg.Dx != 1u || d->cfg.Dy != 1u) return false;
 	const bool half = d->cfg.storage != LBMHIP_FP32;
 	const uint32_t V = half ? 2u : 1u; // the agent-scope accesses move 4 bytes per lane: one FP32 cell or two 16-bit cells
 	if (d->cfg.Nx%V != 0u) return false;
-	*fn = select_collide_pair((int)d->cfg.velocity_set, (int)d->cfg.storage, (int)d->cfg.collision, (int)d->cfg.features, (int)V, (V == 2u && d->pair_cells_together == 2) ? 2 : 1);
-	if (!*fn) return false;
+	plan->k = select_collide_pair((int)d->cfg.velocity_set, (int)d->cfg.storage, (int)d->cfg.collision, (int)d->cfg.features, (int)V, (V == 2u && d->pair_cells_together == 2) ? 2 : 1);
+	if (!plan->k.pair) return false;
 	const uint32_t lanes_per_row = d->cfg.Nx/V;
-	*block = std::min(256u, (lanes_per_row+63u)/64u*64u);
-	*xchunks = (lanes_per_row+*block-1u)/(*block);
-	const uint64_t per_plane = (uint64_t)*xchunks*d->cfg.Ny;
-	if (per_plane*(*block) >= 0xFFFFFFFFull || 2u*d->cfg.Nz > 65535u) return false;
-	*blocks_per_cu = d->pair_blocks_per_cu >= 0 ? d->pair_blocks_per_cu : 0;
-	const uint64_t resident = (uint64_t)d->compute_units*(uint64_t)(*blocks_per_cu > 0 ? std::min(*blocks_per_cu*256/(int)*block, 8*256/(int)*block) : 8*256/(int)*block);
-	*lag = d->pair_lag ? (uint32_t)d->pair_lag : std::max(3u, 2u+(uint32_t)((resident+per_plane-1u)/per_plane));
-	if (d->cfg.Nz < *lag+4u) return false;
+	plan->block = std::min(256u, (lanes_per_row+63u)/64u*64u);
+	plan->xchunks = (lanes_per_row+plan->block-1u)/plan->block;
+	const uint64_t per_plane = (uint64_t)plan->xchunks*d->cfg.Ny;
+	if (per_plane*plan->block >= 0xFFFFFFFFull || 2u*d->cfg.Nz > 65535u) return false;
+	const int per_cu_max = 8*256/(int)plan->block;
+	// band by band on each XCD: blocks of ceil(Ny/8) rows, at least 4 rows each
+	plan->block_rows = (d->cfg.Ny+7u)/8u;
+	const bool band_possible = plan->block_rows >= 4u && d->cfg.Nz >= 8u;
+	plan->mode = (d->fuse == 2 && band_possible) ? 2 : 1;
+	if (plan->mode == 2) {
+		plan->R = std::max(2u, d->band_rows > 0 ? std::min((uint32_t)d->band_rows, plan->block_rows) : std::min(16u, plan->block_rows));
+		plan->bands = (plan->block_rows+plan->R-1u)/plan->R;
+		plan->blocks_per_cu = d->band_blocks_per_cu >= 0 ? d->band_blocks_per_cu : 4;
+		// the workgroups of an XCD that are resident together cover `resident` tasks of its queue; step t+1 follows far enough behind
+		// step t that the workgroups it waits for have left (each plane of a band is R*xchunks tasks of each step)
+		const uint32_t resident = (uint32_t)(d->compute_units/8)*(uint32_t)(plan->blocks_per_cu > 0 ? std::min(plan->blocks_per_cu*256/(int)plan->block, per_cu_max) : per_cu_max);
+		const uint32_t per_band_plane = plan->R*plan->xchunks;
+		plan->lag = d->band_lag ? (uint32_t)d->band_lag : std::max(2u, 2u+(resident+2u*per_band_plane-1u)/(2u*per_band_plane));
+		if (d->cfg.Nz < plan->lag+4u || (uint64_t)8u*per_band_plane*plan->block >= 0xFFFFFFFFull) return false;
+		return true;
+	}
+	plan->blocks_per_cu = d->pair_blocks_per_cu >= 0 ? d->pair_blocks_per_cu : 0;
+	const uint64_t resident = (uint64_t)d->compute_units*(uint64_t)(plan->blocks_per_cu > 0 ? std::min(plan->blocks_per_cu*256/(int)plan->block, per_cu_max) : per_cu_max);
+	plan->lag = d->pair_lag ? (uint32_t)d->pair_lag : std::max(3u, 2u+(uint32_t)((resident+per_plane-1u)/per_plane));
+	if (d->cfg.Nz < plan->lag+4u) return false;
 	const uint64_t plane_bytes = (uint64_t)d->cfg.Nx*d->cfg.Ny*d->cfg.velocity_set*d->fpxx_bytes;
-	if (d->fuse < 0 && ((uint64_t)(*lag+4u)*plane_bytes > kPairWindowBytes || (uint64_t)d->cfg.Nx*d->cfg.Ny < 512ull*512ull || lanes_per_row%256u != 0u ||
+	if (d->fuse < 0 && ((uint64_t)(plan->lag+4u)*plane_bytes > kPairWindowBytes || (uint64_t)d->cfg.Nx*d->cfg.Ny < 512ull*512ull || lanes_per_row%256u != 0u ||
 	                    d->cfg.velocity_set != 19u || d->cfg.collision != LBMHIP_SRT || d->cfg.features != 0u)) return false;
 	return true;
 }
 static int pairs_steps(const lbmhip_domain* d) {
-	lbm::pair_launch_fn fn = nullptr;
-	uint32_t lag = 0u, xchunks = 1u, block = 256u;
-	int blocks_per_cu = 0;
-	if (!pair_plan(d, &fn, &lag, &blocks_per_cu, &xchunks, &block)) return 0;
-	return d->cfg.Dz == 1u || d->cfg.Nz >= lag+10u; // a slab pairs its planes 2 .. Nz-3
+	PairPlan plan;
+	if (!pair_plan(d, &plan)) return 0;
+	return d->cfg.Dz == 1u || d->cfg.Nz >= plan.lag+10u; // a slab pairs its planes 2 .. Nz-3
 }
-static int launch_collide_pair_steps(lbmhip_domain* d, pair_launch_fn fn, uint64_t t, float fx, float fy, float fz, uint32_t lag, int blocks_per_cu, uint32_t xchunks, uint32_t block,
+static void note_pair_used(lbmhip_domain* d, const PairPlan& plan) {
+	d->pair_used = plan.mode; d->pair_used_lag = (int)plan.lag; d->pair_used_blocks_per_cu = plan.blocks_per_cu; d->band_used_rows = plan.mode == 2 ? (int)plan.R : 0;
+}
+static int launch_collide_band_steps(lbmhip_domain* d, const PairPlan& plan, uint64_t t, float fx, float fy, float fz, uint32_t first1, uint32_t count1, uint32_t first2, uint32_t count2) {
+	const uint32_t Nz = d->cfg.Nz, Ny = d->cfg.Ny;
+	// header (16 words: error, redo count) + one counter per (XCD, band, plane); the redo list holds every task of step t+1 at most
+	const uint64_t words = 16u+(uint64_t)8u*plan.bands*Nz, redo_capacity = (uint64_t)Nz*Ny*plan.xchunks;
+	if (words > d->band_sync_words || redo_capacity > d->band_redo_capacity) {
+		HIP_TRY(hipStreamSynchronize(d->stream)); // an earlier launch may still use the old buffers
+		if (d->band_sync) HIP_TRY(hipFree(d->band_sync));
+		if (d->band_redo) HIP_TRY(hipFree(d->band_redo));
+		d->band_sync = nullptr; d->band_redo = nullptr; d->band_sync_words = d->band_redo_capacity = 0u;
+		HIP_TRY(hipMalloc((void**)&d->band_sync, words*sizeof(uint32_t)));
+		HIP_TRY(hipMalloc((void**)&d->band_redo, redo_capacity*sizeof(uint64_t)));
+		d->band_sync_words = words; d->band_redo_capacity = redo_capacity;
+	}
+	NEED(count1+count2 <= 65535u && plan.bands <= 65535u, "too many planes for a two-step launch (%u)", count1+count2);
+	Args a = make_args(d, t, fx, fy, fz);
+	a.xchunks = plan.xchunks; a.z0 = 0u; a.z1 = Nz;
+	BandArgs p;
+	p.error = d->band_sync; p.redo_count = d->band_sync+1; p.done = d->band_sync+16; p.redo = d->band_redo;
+	p.block_rows = plan.block_rows; p.R = plan.R; p.bands = plan.bands; p.lag = plan.lag;
+	p.spin_limit = d->band_spin_limit >= 0 ? (uint32_t)d->band_spin_limit : 60000u; // about 0.2 s of polling (3.4 us of sleep between two polls)
+	p.first1 = first1; p.count1 = count1; p.first2 = first2; p.count2 = count2;
+	HIP_TRY(hipMemsetAsync(d->band_sync, 0, words*sizeof(uint32_t), d->stream));
+	int blocks_per_cu = plan.blocks_per_cu;
+	if (blocks_per_cu > 0) blocks_per_cu = std::max(1, blocks_per_cu*256/(int)plan.block);
+	const uint32_t lds = blocks_per_cu > 0 ? ((160u*1024u/(uint32_t)blocks_per_cu)&~255u)-256u : 0u; // the kernel has a word of LDS of its own
+	HIP_TRY(plan.k.band(a, p, dim3(8u*plan.R*plan.xchunks, count1+count2, plan.bands), dim3(plan.block), lds, d->stream));
+	// step t+1 on the first and the last row of every block, and whatever the launch gave up
+	SeamArgs q;
+	q.nrows = 0u;
+	for (uint32_t b = 0u; b < 8u; b++) {
+		const uint32_t bs = b*plan.block_rows, be = std::min(bs+plan.block_rows, Ny);
+		if (bs >= Ny) break;
+		q.rows[q.nrows++] = bs;
+		if (be-1u > bs) q.rows[q.nrows++] = be-1u;
+	}
+	q.first2 = first2; q.count2 = count2; q.redo_count = p.redo_count; q.redo = p.redo;
+	Args b = make_args(d, t+1u, fx, fy, fz);
+	b.xchunks = plan.xchunks; b.z0 = 0u; b.z1 = Nz;
+	HIP_TRY(plan.k.seam(b, q, dim3(q.nrows*plan.xchunks, count2+1u), dim3(plan.block), 0u, d->stream));
+	d->band_unchecked = 1;
+	return 0;
+}
+static int launch_collide_pair_steps(lbmhip_domain* d, const PairPlan& plan, uint64_t t, float fx, float fy, float fz,
                                      uint32_t first1, uint32_t count1, uint32_t first2, uint32_t count2) {
 	DeviceGuard g(d->cfg.device);
+	if (plan.mode == 2) return launch_collide_band_steps(d, plan, t, fx, fy, fz, first1, count1, first2, count2);
 	Args a = make_args(d, t, fx, fy, fz);
-	a.xchunks = xchunks; a.z0 = 0u; a.z1 = d->cfg.Nz;
+	a.xchunks = plan.xchunks; a.z0 = 0u; a.z1 = d->cfg.Nz;
 	PairArgs p;
 	p.first1 = first1; p.count1 = count1; p.first2 = first2; p.count2 = count2;
 	p.plane_done = d->pair_sync; p.replica_stride = d->pair_replica_stride; p.shard_done = d->pair_sync+(uint64_t)PAIR_REPLICAS*d->pair_replica_stride; p.error = d->pair_sync+d->pair_sync_words-16u;
-	p.lag = lag; p.spin_limit = 500000u; // about two seconds of polling (3.4 us of sleep between two polls)
+	p.lag = plan.lag; p.spin_limit = 500000u; // about two seconds of polling (3.4 us of sleep between two polls)
 	HIP_TRY(hipMemsetAsync(d->pair_sync, 0, (d->pair_sync_words-16u)*sizeof(uint32_t), d->stream));
-	if (blocks_per_cu > 0) blocks_per_cu = std::max(1, blocks_per_cu*256/(int)block);
+	int blocks_per_cu = plan.blocks_per_cu;
+	if (blocks_per_cu > 0) blocks_per_cu = std::max(1, blocks_per_cu*256/(int)plan.block);
 	const uint32_t lds = blocks_per_cu > 0 ? ((160u*1024u/(uint32_t)blocks_per_cu)&~255u) : 0u;
-	HIP_TRY(fn(a, p, dim3(xchunks*d->cfg.Ny, count1+count2), dim3(block), lds, d->stream));
+	HIP_TRY(plan.k.pair(a, p, dim3(plan.xchunks*d->cfg.Ny, count1+count2), dim3(plan.block), lds, d->stream));
 	d->pair_unchecked = 1;
 	return 0;
 }
 int lbmhip_stream_collide_steps(lbmhip_domain* d, uint64_t t, uint32_t steps, float fx, float fy, float fz) {
 	NEED(d, "null domain");
-	pair_launch_fn fn = nullptr;
-	uint32_t lag = 0u, xchunks = 1u, block = 256u, done = 0u;
-	int blocks_per_cu = 0;
+	PairPlan plan;
+	uint32_t done = 0u;
 	d->pair_used = 0;
-	if (steps >= 2u && d->cfg.Dz == 1u && pair_plan(d, &fn, &lag, &blocks_per_cu, &xchunks, &block)) {
-		for (; steps-done >= 2u; done += 2u) { const int status = launch_collide_pair_steps(d, fn, t+done, fx, fy, fz, lag, blocks_per_cu, xchunks, block, 0u, d->cfg.Nz, 2u, d->cfg.Nz); if (status) return status; }
-		d->pair_used = 1; d->pair_used_lag = (int)lag; d->pair_used_blocks_per_cu = blocks_per_cu;
+	if (steps >= 2u && d->cfg.Dz == 1u && pair_plan(d, &plan)) {
+		// the whole periodic lattice: step t+1 starts behind the seam (k_collide_pair asks for the planes p-2..p+2, k_collide_band for p-1..p+1)
+		for (; steps-done >= 2u; done += 2u) { const int status = launch_collide_pair_steps(d, plan, t+done, fx, fy, fz, 0u, d->cfg.Nz, plan.mode == 2 ? 1u : 2u, d->cfg.Nz); if (status) return status; }
+		note_pair_used(d, plan);
 	}
 	for (; done < steps; done++) { const int status = launch_collide_planes(d, t+done, fx, fy, fz, 0u, d->cfg.Nz, false); if (status) return status; }
 	return 0;
@@ -746,14 +838,12 @@ int lbmhip_stream_collide_pair_planes(lbmhip_domain* d, uint64_t t, float fx, fl
 	NEED(d, "null domain");
 	NEED(z_begin <= z_end && z_end <= d->cfg.Nz, "plane range [%u, %u) outside the lattice (Nz=%u)", z_begin, z_end, d->cfg.Nz);
 	NEED(d->cfg.Dz == 1u || (z_begin >= 1u && z_end <= d->cfg.Nz-1u), "plane range [%u, %u) includes a halo plane", z_begin, z_end);
-	pair_launch_fn fn = nullptr;
-	uint32_t lag = 0u, xchunks = 1u, block = 256u;
-	int blocks_per_cu = 0;
+	PairPlan plan;
 	d->pair_used = 0;
-	if (z_end-z_begin >= 5u && pair_plan(d, &fn, &lag, &blocks_per_cu, &xchunks, &block) && z_end-z_begin >= lag+6u) {
-		const int status = launch_collide_pair_steps(d, fn, t, fx, fy, fz, lag, blocks_per_cu, xchunks, block, z_begin, z_end-z_begin, z_begin+2u, z_end-z_begin-4u);
+	if (z_end-z_begin >= 5u && pair_plan(d, &plan) && z_end-z_begin >= plan.lag+6u) {
+		const int status = launch_collide_pair_steps(d, plan, t, fx, fy, fz, z_begin, z_end-z_begin, z_begin+2u, z_end-z_begin-4u);
 		if (status) return status;
-		d->pair_used = 1; d->pair_used_lag = (int)lag; d->pair_used_blocks_per_cu = blocks_per_cu;
+		note_pair_used(d, plan);
 		return 0;
 	}
 	int status = launch_collide_planes(d, t, fx, fy, fz, z_begin, z_end, false);

@@ -29,6 +29,12 @@ def fused_flag(lbm):
     return v.value
 
 
+def tuning(lbm, key):
+    v = C.c_int(-1)
+    cfd_amd.lbm.check(cfd_amd.lib().lbmhip_get_tuning(lbm.domains[0].h, key.encode(), C.byref(v)))
+    return v.value
+
+
 def bits(a):
     return a.view(np.uint32 if a.dtype == np.float32 else np.uint16)
 
@@ -53,6 +59,70 @@ def test_paired_steps_equal_single_steps(gpu, kw, setup, steps, together, lag, c
         assert np.array_equal(bits(a.domains[0].download_fi()), bits(b.domains[0].download_fi())), "DDFs differ after the odd step"
     finally:
         a.close(); b.close()
+
+
+BAND_TGV = dict(N=(96, 72, 24), nu=0.02)                     # blocks of 9 rows
+BAND_RAGGED = dict(N=(320, 45, 20), nu=0.01, features=("VOLUME_FORCE", "SUBGRID"), f=(2e-4, 0.0, 0.0), collision="TRT")  # blocks of 6 rows, the last one of 3; rows of two chunks
+
+
+@pytest.mark.parametrize("rows,lag,cap", [(16, 2, 0), (3, 2, 0), (4, 5, 2), (2, 3, 4), (64, 4, 3)])
+@pytest.mark.parametrize("kw,setup,steps,together", [(TGV, setups.taylor_green, 7, 1), (BAND_TGV, setups.taylor_green, 6, 1), (BAND_RAGGED, setups.channel, 6, 1), (CHANNEL, setups.channel, 6, 1),
+                                                     (Q27, setups.taylor_green, 4, 1), (HALF_S, setups.taylor_green, 6, 1), (HALF_S, setups.taylor_green, 5, 2), (HALF_C, setups.taylor_green, 6, 1)])
+def test_banded_steps_equal_single_steps(gpu, kw, setup, steps, together, rows, lag, cap):
+    """Two steps per launch band by band on each XCD (fuse = 2): every band height (two rows, bands that do not divide the block, a
+    band larger than the block), short and long lags, with and without a residency cap - always the bits of single launches."""
+    a = cfd_amd.LBM(**kw); b = cfd_amd.LBM(**kw)
+    try:
+        for lbm, fuse in ((a, 2), (b, 0)):
+            lbm.set_tuning("fuse", fuse)
+            setup(lbm)
+        a.set_tuning("band_rows", rows); a.set_tuning("band_lag", lag); a.set_tuning("band_blocks_per_cu", cap); a.set_tuning("pair_cells_together", together)
+        a.run(steps); b.run(steps)
+        assert fused_flag(a) == 2 and fused_flag(b) == 0
+        assert np.array_equal(bits(a.domains[0].download_fi()), bits(b.domains[0].download_fi())), "DDFs differ"
+        a.read_from_device(); b.read_from_device()
+        assert np.array_equal(bits(a.rho), bits(b.rho)) and np.array_equal(bits(a.u), bits(b.u))
+        assert tuning(a, "band_given_up") == 0
+        a.run(1); b.run(1)  # a single step after paired ones
+        assert fused_flag(a) == 0
+        assert np.array_equal(bits(a.domains[0].download_fi()), bits(b.domains[0].download_fi())), "DDFs differ after the odd step"
+    finally:
+        a.close(); b.close()
+
+
+def test_banded_waits_that_run_out_are_redone(gpu):
+    """A wait that gives up at once (no polls allowed, lag 2: the first step's workgroups are still running) leaves its task to the
+    launch behind; the lattice is still that of single launches, the library reports it and stops pairing."""
+    kw = dict(N=(128, 64, 32), nu=0.02)
+    a = cfd_amd.LBM(**kw); b = cfd_amd.LBM(**kw)
+    try:
+        a.set_tuning("fuse", 2); b.set_tuning("fuse", 0)
+        a.set_tuning("band_rows", 4); a.set_tuning("band_lag", 2); a.set_tuning("band_spin_limit", 0)
+        setups.taylor_green(a); setups.taylor_green(b)
+        a.run(6); b.run(6)
+        assert np.array_equal(bits(a.domains[0].download_fi()), bits(b.domains[0].download_fi())), "DDFs differ"
+        assert tuning(a, "band_given_up") >= 1 and tuning(a, "fuse") == 0
+        a.run(4); b.run(4)
+        assert fused_flag(a) == 0
+        assert np.array_equal(bits(a.domains[0].download_fi()), bits(b.domains[0].download_fi()))
+    finally:
+        a.close(); b.close()
+
+
+@pytest.mark.parametrize("kw,setup", [(CHANNEL, setups.channel), (HALF_S, setups.taylor_green), (BAND_RAGGED, setups.channel)])
+def test_banded_steps_equal_the_oracle(gpu, kw, setup):
+    a = cfd_amd.LBM(**kw); b = H.OracleLBM(**kw)
+    try:
+        a.set_tuning("fuse", 2); a.set_tuning("band_rows", 4); a.set_tuning("band_lag", 2)
+        setup(a); setup(b)
+        a.run(12); b.run(12)
+        assert fused_flag(a) == 2
+        assert np.array_equal(bits(a.domains[0].download_fi()), bits(b.domains[0].fi)), "DDFs differ from the oracle"
+        a.read_from_device(); b.read_from_device()
+        assert np.array_equal(a.flags, b.flags)
+        assert np.array_equal(bits(a.rho), bits(b.rho)) and np.array_equal(bits(a.u), bits(b.u))
+    finally:
+        a.close()
 
 
 @pytest.mark.parametrize("kw,setup", [(CHANNEL, setups.channel), (HALF_S, setups.taylor_green), (HALF_C, setups.taylor_green)])

@@ -1,7 +1,9 @@
 """Diagnostic: step rate of lbmhip_stream_collide_steps (two time steps per launch) over its lag and residency cap,
 against one launch per step.  (GPU needed)
 
-usage: [SWEEP_CAPS=0,6,4,3] [SWEEP_LAGS=3,4,5,6,7,8] python tools/fused_sweep.py [n] [config: tgv|channel] [storage] [cells collided together in the paired kernel: 1|2]
+usage: [SWEEP_CAPS=0,6,4,3] [SWEEP_LAGS=3,4,5,6,7,8] [SWEEP_BAND_ROWS=8,16] [SWEEP_BAND_LAGS=0,3,4] [SWEEP_BAND_CAPS=3,4,0]
+       python tools/fused_sweep.py [n] [config: tgv|channel] [storage] [cells collided together in the paired kernel: 1|2]
+SWEEP_CAPS / SWEEP_LAGS empty: skip the sweep of k_collide_pair; SWEEP_BAND_ROWS (default empty) sweeps k_collide_band (lag 0 = automatic).
 """
 import ctypes as C
 import sys
@@ -49,10 +51,22 @@ print("%s %s %d^3 one launch per step: %.3f ms/step %7.0f MLUPs/s %.1f %% of 8 T
 lbm.set_tuning("fuse", 1)
 lbm.set_tuning("pair_cells_together", together)
 import os
-caps = [int(v) for v in os.environ.get("SWEEP_CAPS", "0,6,4,3").split(",")]
-lags = [int(v) for v in os.environ.get("SWEEP_LAGS", "3,4,5,6,7,8").split(",")]
+def ints(name, default):
+    return [int(v) for v in os.environ.get(name, default).split(",") if v.strip()]
+
+
+caps = ints("SWEEP_CAPS", "0,6,4,3")
+lags = ints("SWEEP_LAGS", "3,4,5,6,7,8")
 for cap in caps:
     for lag in lags:
         lbm.set_tuning("pair_lag", lag); lbm.set_tuning("pair_blocks_per_cu", cap)
         print("%s %s %d^3 two steps per launch, lag %d, blocks/CU<=%d: %.3f ms/step %7.0f MLUPs/s %.1f %% of 8 TB/s" % ((config, storage, n, lag, cap) + rate(40)), flush=True)
+lbm.set_tuning("fuse", 2)
+for rows in ints("SWEEP_BAND_ROWS", ""):
+    for cap in ints("SWEEP_BAND_CAPS", "3,4,0"):
+        for lag in ints("SWEEP_BAND_LAGS", "0,3,4,6"):
+            lbm.set_tuning("band_rows", rows); lbm.set_tuning("band_lag", lag); lbm.set_tuning("band_blocks_per_cu", cap)
+            r = rate(40)
+            print("%s %s %d^3 two steps per launch band by band, %d rows, lag %d (%d), blocks/CU<=%d: %.3f ms/step %7.0f MLUPs/s %.1f %% of 8 TB/s, given up %d" %
+                  ((config, storage, n, rows, lag, lbm.get_tuning("band_lag"), cap) + r + (lbm.get_tuning("band_given_up"),)), flush=True)
 lbm.close()
