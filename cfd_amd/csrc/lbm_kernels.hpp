@@ -596,26 +596,34 @@ __global__ __launch_bounds__(256, (P == 2 && V == 2 ? 3 : 1)) void k_collide_pai
 //   few hundred KB per plane of the band.  The first and the last row of every block need step t from a neighbouring XCD:
 //   their step t+1 is left to k_collide_seam, a launch of its own behind this one (16 of Ny rows per plane).
 //   Hand-over inside an XCD: step t stores plainly (the lines stay in the XCD's L2, dirty), every wave drains its stores
-//   (s_waitcnt vmcnt(0): acknowledged by the L2), the workgroup passes a barrier and one lane counts it done on the counter
-//   of (XCD it ran on, band, plane) - the XCD is read from the hardware register, not inferred.  Step t+1 polls the counters
-//   of ITS XCD with agent-scope loads, passes a barrier and loads its DDFs past the L1 (sc1: served by the L2, which is the
-//   one copy all CUs of an XCD share; the same order makes workgroup scope coherent when the waves of one workgroup run on
-//   several CUs of an XCD).  Were the workgroups dealt differently, a counter would never fill and nothing stale be read:
-//   the wait is bounded, a wait that runs out raises *error, every other wait sees that and gives up too, and a workgroup
-//   that gives up writes its task to the redo list and computes nothing.  k_collide_seam then runs those tasks (step t is
-//   complete by then and nothing in the launch depends on step t+1), so the lattice is right in every case and only the
-//   time is lost; the host turns the pairing off when it finds *error set.
+//   (s_waitcnt vmcnt(0): acknowledged by the L2), the workgroup passes a barrier and one lane stores the workgroup's stamp -
+//   the launch's number and the XCD it ran on, read from the hardware register, not inferred - again plainly, into the word
+//   of its task.  Step t+1 loads the stamps of the (at most 27) step-t tasks it depends on - rows y-1..y+1, planes z-1..z+1,
+//   its own x chunk and the two beside it - past the L1 (sc1: served by the L2, the one copy all CUs of an XCD share; the same
+//   order makes workgroup scope coherent when the waves of one workgroup run on several CUs of an XCD), passes a barrier and
+//   loads its DDFs the same way.  Stamps and DDFs never leave the XCD between the two steps: no atomic, no word that the
+//   whole chip polls (counters that 500 000 workgroups add to and ask about through one memory channel cost more than the
+//   second step's reads save: 50 % of 8 TB/s against 86 % with the waits switched off).  A stamp of this launch that names
+//   another XCD means the workgroups were not dealt as assumed; then, and when a wait runs out, the workgroup raises *error,
+//   writes its task to the redo list and computes nothing, and every other wait that finds a stamp missing looks at *error
+//   and gives up too.  k_collide_seam runs the tasks of the list (step t is complete by then and nothing in the launch depends
+//   on step t+1), so the lattice is right in every case and only time is lost; the host turns the pairing off when it finds
+//   *error set.
 struct BandArgs {
-	uint32_t* done;        // [8 XCDs][bands per block][Nz]: step-t workgroups that have finished (zeroed before the launch)
+	uint32_t* stamps;      // [8 blocks][bands][Nz][R][xchunks]: (launch number << 3 | XCD) of every finished step-t task; never cleared, launch numbers rise
+	uint32_t stamp;        // this launch's number << 3
 	uint32_t* error;       // raised by a wait that ran out (zeroed before the launch)
 	uint32_t* redo_count;  // tasks of step t+1 given up (zeroed before the launch)
 	uint64_t* redo;        // their (z*Ny+y)*xchunks+chunk
 	uint32_t block_rows;   // rows per XCD block
-	uint32_t R, bands;     // rows per band (>= 2: the two rows above a band lie in the band before it), bands per block
+	uint32_t R, bands;     // rows per band, bands per block
 	uint32_t lag;          // >= 2: step t+1 on plane first2+j follows step t on plane first2+j+lag-1
 	uint32_t spin_limit;   // polls before a wait gives up
 	uint32_t first1, count1, first2, count2; // planes of step t and of step t+1 (modulo Nz), as in PairArgs but first2 >= first1+1 suffices
 };
+#ifndef LBM_BAND_EXP
+#define LBM_BAND_EXP 0 // diagnostic builds (tools/band_variants.sh): 1 no waits, 2 plain loads in step t+1, 4 write-through stores in step t, 32 wait statistics - 1 gives wrong lattices
+#endif
 __device__ __forceinline__ uint32_t xcd_of_this_wave() { uint32_t x; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(x)); return x&7u; }
 template <int Q, int ST, int COLL, int FEAT, int V = 1, int P = 1>
 __global__ __launch_bounds__(256, (P == 2 && V == 2 ? 3 : 1)) void k_collide_band(const Args a, const BandArgs p) {
@@ -636,11 +644,12 @@ __global__ __launch_bounds__(256, (P == 2 && V == 2 ? 3 : 1)) void k_collide_ban
 		const uint32_t y = b0+row;
 		if (y >= b1) return;
 		__builtin_amdgcn_s_setprio(2); // step t is what step t+1 waits for
-		if constexpr (V == 1) collide_row<Q, ST, COLL, FEAT, false>(a, chunk, y, z);
-		else collide_row_wide<Q, ST, COLL, FEAT, V, P>(a, chunk, y, z);
+		constexpr int MEM1 = (LBM_BAND_EXP&4) ? MEM_STORE_THROUGH : MEM_PLAIN;
+		if constexpr (V == 1) collide_row<Q, ST, COLL, FEAT, false, MEM1>(a, chunk, y, z);
+		else collide_row_wide<Q, ST, COLL, FEAT, V, P, false, MEM1>(a, chunk, y, z);
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's stores have been acknowledged by the L2
 		__syncthreads();
-		if (threadIdx.x == 0u) __hip_atomic_fetch_add(p.done+((uint64_t)(xcd*p.bands+band)*Nz+z), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (threadIdx.x == 0u) *(volatile uint32_t*)(p.stamps+((((uint64_t)block_of*p.bands+band)*Nz+z)*p.R+row)*a.xchunks+chunk) = p.stamp|xcd;
 	} else {
 		// rows b0-1 .. b1-2; the block's first row and the row above it, and the block's last row, are not this launch's
 		const uint32_t lo = band == 0u ? bs+1u : max(b0-1u, bs+1u), hi = b1 == be ? be-1u : b1-1u;
@@ -650,22 +659,45 @@ __global__ __launch_bounds__(256, (P == 2 && V == 2 ? 3 : 1)) void k_collide_ban
 		uint32_t early = 0u;
 		if (x < a.Nx) early = ld<uint8_t>(a.flags+((uint64_t)z*a.Ny+y)*a.Nx, x); // flags are never written by a step
 		if (threadIdx.x < 64u) {
-			// lanes 0..2: the band's own counters of the planes z-1..z+1; lanes 3..5: those of the band above (swept before), whose last
-			// two rows the rows b0-1 and b0 need; lane 6: the error word
-			const uint32_t lane = threadIdx.x, prev = lane >= 3u ? 1u : 0u;
-			const uint32_t zz = (z+Nz-1u+(lane < 6u ? lane-3u*prev : 0u))%Nz;
-			const bool asked = lane < 6u && (zz+Nz-p.first1)%Nz < p.count1 && (!prev || (band > 0u && y <= b0)); // planes outside this launch's step t were finished by earlier launches
-			const uint32_t need = (prev ? p.R : b1-b0)*a.xchunks;
-			const uint32_t* const word = lane == 6u ? p.error : p.done+((uint64_t)(xcd*p.bands+(asked && prev ? band-1u : band))*Nz+zz);
+			// lane = (plane z-1..z+1) * 9 + (row y-1..y+1) * 3 + (chunk-1..chunk+1, periodic; the same chunk twice in short rows is harmless)
+			const uint32_t lane = threadIdx.x, dz = lane/9u, dr = (lane/3u)%3u, dc = lane%3u;
+			const uint32_t zz = (z+Nz-1u+(lane < 27u ? dz : 0u))%Nz;
+			const bool asked = lane < 27u && (zz+Nz-p.first1)%Nz < p.count1; // planes outside this launch's step t were finished by earlier launches
+			uint32_t bb = (y-1u-bs)/p.R, rr = (y-1u-bs)%p.R+dr; // the rows y-1..y+1 lie inside the block: bs < y < be-1
+			if (rr >= p.R) { rr -= p.R; bb++; }
+			if (rr >= p.R) { rr -= p.R; bb++; } // bands of two rows
+			const uint32_t cc = (chunk+a.xchunks+dc-1u)%a.xchunks;
+			const uint32_t* const word = lane == 27u ? p.error : p.stamps+((((uint64_t)block_of*p.bands+bb)*Nz+zz)*p.R+rr)*a.xchunks+cc;
+			const uint32_t want = p.stamp|xcd;
 			bool failed = false;
-			for (uint32_t spins = 0u; ; spins++) {
+#if LBM_BAND_EXP&32
+			const uint64_t t_begin = __builtin_readcyclecounter();
+			uint32_t polls = 0u;
+#endif
+			for (uint32_t spins = 0u; !(LBM_BAND_EXP&1); spins++) {
+#if LBM_BAND_EXP&32
+				polls++;
+#endif
 				uint32_t v = 0u;
-				if (asked || lane == 6u) v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				if (__ballot(lane == 6u && v != 0u) != 0ull) { failed = true; break; }
-				if (__ballot(asked && v < need) == 0ull) break;
-				if (spins >= p.spin_limit) { if (lane == 0u) __hip_atomic_store(p.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); failed = true; break; }
+				if (asked || (lane == 27u && spins > 0u)) v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // the error word only once a stamp was found missing
+				if (__ballot(asked && v != want) == 0ull) break;
+				const bool elsewhere = asked && (v&~7u) == p.stamp && v != want; // finished, on another XCD: its DDFs may sit in that XCD's L2
+				if (__ballot(elsewhere || (lane == 27u && v != 0u)) != 0ull || spins >= p.spin_limit) {
+					if (lane == 0u) __hip_atomic_store(p.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					failed = true;
+					break;
+				}
 				if (spins < 2u) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(127);
 			}
+#if LBM_BAND_EXP&32
+			if (lane == 0u) { // header words 4..: step-t+1 workgroups, polls, workgroups that polled more than once / more than three times, cycles between the first poll and the last
+				__hip_atomic_fetch_add(p.error+4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__hip_atomic_fetch_add(p.error+5, polls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (polls > 1u) __hip_atomic_fetch_add(p.error+6, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(p.error+8), (unsigned long long)(__builtin_readcyclecounter()-t_begin), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (polls > 3u) __hip_atomic_fetch_add(p.error+7, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+#endif
 			if (lane == 0u) {
 				give_up = failed ? 1u : 0u;
 				if (failed) p.redo[__hip_atomic_fetch_add(p.redo_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = ((uint64_t)z*a.Ny+y)*a.xchunks+chunk;
@@ -675,10 +707,11 @@ __global__ __launch_bounds__(256, (P == 2 && V == 2 ? 3 : 1)) void k_collide_ban
 		if (give_up) return;
 		Args b = a;
 		b.odd = a.odd^1u;
-		if constexpr (V == 1) collide_row<Q, ST, COLL, FEAT, false, MEM_LOAD_COHERENT, true>(b, chunk, y, z, early);
+		constexpr int MEM2 = (LBM_BAND_EXP&2) ? MEM_PLAIN : MEM_LOAD_COHERENT;
+		if constexpr (V == 1) collide_row<Q, ST, COLL, FEAT, false, MEM2, true>(b, chunk, y, z, early);
 		else {
 			asm volatile("" :: "v"(early));
-			collide_row_wide<Q, ST, COLL, FEAT, V, P, false, MEM_LOAD_COHERENT>(b, chunk, y, z);
+			collide_row_wide<Q, ST, COLL, FEAT, V, P, false, MEM2>(b, chunk, y, z);
 		}
 	}
 }

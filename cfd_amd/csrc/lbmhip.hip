@@ -60,6 +60,7 @@ struct lbmhip_domain {
 	uint32_t* band_sync; uint64_t band_sync_words; uint64_t* band_redo; uint64_t band_redo_capacity;
 	int band_rows, band_lag, band_blocks_per_cu; // rows per band, lag in planes, residency cap: 0 / 0 / -1 = automatic
 	int band_spin_limit, band_used_rows;
+	uint32_t band_launches; // number of the last k_collide_band launch (the stamp its workgroups leave)
 	int band_unchecked, band_given_up;            // launches since the error word was last read; launches found to have given up waits (their tasks were redone)
 	int compute_units;
 };
@@ -763,26 +764,29 @@ static void note_pair_used(lbmhip_domain* d, const PairPlan& plan) {
 }
 static int launch_collide_band_steps(lbmhip_domain* d, const PairPlan& plan, uint64_t t, float fx, float fy, float fz, uint32_t first1, uint32_t count1, uint32_t first2, uint32_t count2) {
 	const uint32_t Nz = d->cfg.Nz, Ny = d->cfg.Ny;
-	// header (16 words: error, redo count) + one counter per (XCD, band, plane); the redo list holds every task of step t+1 at most
-	const uint64_t words = 16u+(uint64_t)8u*plan.bands*Nz, redo_capacity = (uint64_t)Nz*Ny*plan.xchunks;
-	if (words > d->band_sync_words || redo_capacity > d->band_redo_capacity) {
+	// header (64 words: error, redo count; zeroed before every launch) + one stamp per step-t task (never cleared: the launch
+	// numbers in them rise); the redo list holds every task of step t+1 at most
+	const uint64_t header = 64u, words = header+(uint64_t)8u*plan.bands*Nz*plan.R*plan.xchunks, redo_capacity = (uint64_t)Nz*Ny*plan.xchunks;
+	if (words != d->band_sync_words || redo_capacity > d->band_redo_capacity || d->band_launches >= (1u<<28)) { // another band height lays the stamps out differently
 		HIP_TRY(hipStreamSynchronize(d->stream)); // an earlier launch may still use the old buffers
 		if (d->band_sync) HIP_TRY(hipFree(d->band_sync));
 		if (d->band_redo) HIP_TRY(hipFree(d->band_redo));
 		d->band_sync = nullptr; d->band_redo = nullptr; d->band_sync_words = d->band_redo_capacity = 0u;
 		HIP_TRY(hipMalloc((void**)&d->band_sync, words*sizeof(uint32_t)));
 		HIP_TRY(hipMalloc((void**)&d->band_redo, redo_capacity*sizeof(uint64_t)));
-		d->band_sync_words = words; d->band_redo_capacity = redo_capacity;
+		HIP_TRY(fill_words(d->band_sync, 0u, words, d->stream));
+		d->band_sync_words = words; d->band_redo_capacity = redo_capacity; d->band_launches = 0u;
 	}
 	NEED(count1+count2 <= 65535u && plan.bands <= 65535u, "too many planes for a two-step launch (%u)", count1+count2);
 	Args a = make_args(d, t, fx, fy, fz);
 	a.xchunks = plan.xchunks; a.z0 = 0u; a.z1 = Nz;
 	BandArgs p;
-	p.error = d->band_sync; p.redo_count = d->band_sync+1; p.done = d->band_sync+16; p.redo = d->band_redo;
+	p.error = d->band_sync; p.redo_count = d->band_sync+1; p.stamps = d->band_sync+header; p.redo = d->band_redo;
+	p.stamp = ++d->band_launches<<3;
 	p.block_rows = plan.block_rows; p.R = plan.R; p.bands = plan.bands; p.lag = plan.lag;
 	p.spin_limit = d->band_spin_limit >= 0 ? (uint32_t)d->band_spin_limit : 60000u; // about 0.2 s of polling (3.4 us of sleep between two polls)
 	p.first1 = first1; p.count1 = count1; p.first2 = first2; p.count2 = count2;
-	HIP_TRY(hipMemsetAsync(d->band_sync, 0, words*sizeof(uint32_t), d->stream));
+	HIP_TRY(hipMemsetAsync(d->band_sync, 0, header*sizeof(uint32_t), d->stream));
 	int blocks_per_cu = plan.blocks_per_cu;
 	if (blocks_per_cu > 0) blocks_per_cu = std::max(1, blocks_per_cu*256/(int)plan.block);
 	const uint32_t lds = blocks_per_cu > 0 ? ((160u*1024u/(uint32_t)blocks_per_cu)&~255u)-256u : 0u; // the kernel has a word of LDS of its own
@@ -801,6 +805,14 @@ static int launch_collide_band_steps(lbmhip_domain* d, const PairPlan& plan, uin
 	b.xchunks = plan.xchunks; b.z0 = 0u; b.z1 = Nz;
 	HIP_TRY(plan.k.seam(b, q, dim3(q.nrows*plan.xchunks, count2+1u), dim3(plan.block), 0u, d->stream));
 	d->band_unchecked = 1;
+	if (getenv("LBMHIP_BAND_STATS")) { // diagnostic builds with LBM_BAND_EXP&32: what the waits of this launch cost
+		uint32_t h[16];
+		HIP_TRY(hipStreamSynchronize(d->stream));
+		HIP_TRY(hipMemcpy(h, d->band_sync, sizeof(h), hipMemcpyDeviceToHost));
+		unsigned long long cycles; memcpy(&cycles, h+8, 8);
+		fprintf(stderr, "lbmhip band stats: %u waiting workgroups, %.2f polls each, %.1f %% polled more than once, %.1f %% more than three times, %.0f cycles per wait\n", h[4], h[4] ? (double)h[5]/h[4] : 0.0,
+		        h[4] ? 100.0*h[6]/h[4] : 0.0, h[4] ? 100.0*h[7]/h[4] : 0.0, h[4] ? (double)cycles/h[4] : 0.0);
+	}
 	return 0;
 }
 static int launch_collide_pair_steps(lbmhip_domain* d, const PairPlan& plan, uint64_t t, float fx, float fy, float fz,
