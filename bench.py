@@ -16,7 +16,8 @@ headline kind two steps per launch - the same bits as K single launches):
              512^3 cells per GPU, weak scaling
   q27_force  the same geometry, D3Q27 FP16C + FORCE_FIELD + VOLUME_FORCE, strong scaling: a fixed global lattice
              (2048^3, or the largest 2048 x 2048 x Nz that fits the GPUs in use) split into N z-slabs
-Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line; for the default configuration it also carries
+the same lattice measured with FP16S DDFs ("fp16s": the metric is quoted for both), and for N > 1 where every rank sat ("config.ranks").
 """
 import argparse
 import ctypes as C
@@ -141,6 +142,7 @@ def main():
     ap.add_argument("--storage", default=None, choices=["FP32", "FP16S", "FP16C"], help="DDF storage (default: the configuration's own)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--no-fp16s", action="store_true", help="skip the second measurement (the same lattice with FP16S DDFs) of the default configuration")
     ap.add_argument("--no-fuse", action="store_true", help="one launch per step also where the library would run two steps per launch")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse several ranks on one GPU)")
     a = ap.parse_args()
@@ -177,73 +179,107 @@ def main():
         dist.broadcast_object_list(box, src=0)
         N, reduced = tuple(box[0]), box[1]
     lean = a.config != "tgv"  # slabs of up to 10^9 cells: no host copy of the fields, flags go up plane by plane
-    lbm = DistributedLBM(N, 0.01, Q=cfg["Q"], storage=a.storage, collision=cfg["collision"], features=cfg["features"], f=cfg["f"],
-                         rank=rank, world=world, overlap=not a.no_overlap, host_fields=not lean)
-    N = lbm.N
-    if lean:
-        mask = setups.obstacle_mask(N[0], N[1], seed=42)
-        lbm.fill_planes(lambda z: {"flags": setups.channel_flag_plane(N[0], N[1], N[2], z, 42, mask)})
-    else:
-        setups.taylor_green(lbm)
-    lbm.initialize()
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    if a.no_fuse:
-        check(lib.lbmhip_set_tuning(lbm.ops.dom.h, b"fuse", 0))
-        lbm.pair_steps = False
-    # untimed: the library tries its launch geometries on the first full-lattice launches and keeps the fastest
-    # (a lattice whose steps are paired needs no search: the odd step of a call at most runs the single-step kernel)
-    tuned, fused = C.c_int(0), C.c_int(0)
-    for _ in range(TUNE_STEPS // 20):
-        lbm.run(20)
-        check(lib.lbmhip_get_tuning(lbm.ops.dom.h, b"tuned", C.byref(tuned)))
-        check(lib.lbmhip_get_tuning(lbm.ops.dom.h, b"fused", C.byref(fused)))
-        if tuned.value or fused.value:
-            break
-    lbm.run(a.warmup)
-    barrier()
-    ms_events = C.c_float()
-    t0 = time.perf_counter()
-    check(lib.lbmhip_timer_start(lbm.ops.dom.h))          # HIP events on the stream the kernels are launched on
-    lbm.run(a.steps)   # one rank: one lbmhip_stream_collide_steps call; slabs: the steps two at a time around the halo exchanges (DistributedLBM.run)
-    check(lib.lbmhip_timer_stop(lbm.ops.dom.h, C.byref(ms_events)))
-    barrier()
-    own_seconds = time.perf_counter() - t0
-    seconds, per_rank = own_seconds, [own_seconds]
-    if world > 1:
-        t = torch.tensor([own_seconds], dtype=torch.float64, device="cuda")
-        every = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(every, t)
-        per_rank = [float(v.item()) for v in every]
-        seconds = max(per_rank)
+    def measure(storage):
+        """The K timed steps of this configuration with `storage` DDFs: (lattice, seconds of the slowest rank, seconds per rank,
+        milliseconds between HIP events on the launch stream, launch geometry, overlap flag)."""
+        lbm = DistributedLBM(N, 0.01, Q=cfg["Q"], storage=storage, collision=cfg["collision"], features=cfg["features"], f=cfg["f"],
+                             rank=rank, world=world, overlap=not a.no_overlap, host_fields=not lean)
+        n = lbm.N
+        if lean:
+            mask = setups.obstacle_mask(n[0], n[1], seed=42)
+            lbm.fill_planes(lambda z: {"flags": setups.channel_flag_plane(n[0], n[1], n[2], z, 42, mask)})
+        else:
+            setups.taylor_green(lbm)
+        lbm.initialize()
+        h = lbm.ops.dom.h
+        if a.no_fuse:
+            check(lib.lbmhip_set_tuning(h, b"fuse", 0))
+            lbm.pair_steps = False
+        # untimed: the library tries its launch geometries on the first full-lattice launches and keeps the fastest
+        # (a lattice whose steps are paired needs no search: the odd step of a call at most runs the single-step kernel)
+        tuned, fused = C.c_int(0), C.c_int(0)
+        for _ in range(TUNE_STEPS // 20):
+            lbm.run(20)
+            check(lib.lbmhip_get_tuning(h, b"tuned", C.byref(tuned)))
+            check(lib.lbmhip_get_tuning(h, b"fused", C.byref(fused)))
+            if tuned.value or fused.value:
+                break
+        lbm.run(a.warmup)
+        barrier()
+        ms_events = C.c_float()
+        t0 = time.perf_counter()
+        check(lib.lbmhip_timer_start(h))          # HIP events on the stream the kernels are launched on
+        lbm.run(a.steps)   # one rank: one lbmhip_stream_collide_steps call; slabs: the steps two at a time around the halo exchanges (DistributedLBM.run)
+        check(lib.lbmhip_timer_stop(h, C.byref(ms_events)))
+        barrier()
+        own_seconds = time.perf_counter() - t0
+        seconds, per_rank = own_seconds, [own_seconds]
+        if world > 1:
+            t = torch.tensor([own_seconds], dtype=torch.float64, device="cuda")
+            every = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(every, t)
+            per_rank = [float(v.item()) for v in every]
+            seconds = max(per_rank)
+        geometry = {}
+        check(lib.lbmhip_get_tuning(h, b"fused", C.byref(fused)))  # of the timed call
+        keys = {0: ("tuned", "cells_per_thread", "cells_together", "blocks_per_cu", "block", "jit"), 1: ("pair_lag", "pair_blocks_per_cu"),
+                2: ("band_rows", "band_lag", "band_blocks_per_cu", "band_given_up")}[fused.value]
+        for key in keys:
+            v = C.c_int(); check(lib.lbmhip_get_tuning(h, key.encode(), C.byref(v))); geometry[key] = v.value
+        geometry["steps_per_launch"] = 2 if fused.value else 1
+        geometry["kernel"] = {0: "stream_collide", 1: "stream_collide, two steps per launch (k_collide_pair)",
+                              2: "stream_collide, two steps per launch (k_collide_band + k_collide_seam)"}[fused.value]
+        overlap = bool(lbm.overlap)
+        lbm.close()
+        return n, seconds, per_rank, ms_events.value, geometry, overlap
+
+    def roofline(storage, n, ms_events, geometry, workload):
+        """Algorithmic bytes of a launch (SURVEY byte model x cells x steps per launch) over the time of a launch between HIP events."""
+        B = lib.lbmhip_bandwidth_bytes_per_cell(cfg["Q"], STORAGE[storage], feature_mask(cfg["features"]))
+        cells_rank = n[0] * n[1] * (n[2] // world)
+        spl = geometry["steps_per_launch"]
+        kernel_ms = ms_events / a.steps * spl   # per launch (two steps per launch: the launch that pairs them and, band by band, the short one that finishes its block edges)
+        achieved = B * cells_rank * spl / (kernel_ms * 1e-3) / 1e9
+        suffix = {1: "", 2: "_2steps"}[spl] + ("_band" if "band_rows" in geometry else "")
+        traffic, traffic_source = measured_traffic(workload + suffix) if world == 1 else (None, None)
+        r = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+             "traffic": traffic, "traffic_source": traffic_source, "kernel": geometry["kernel"],
+             "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": B * cells_rank * spl}
+        if spl > 1:
+            r["note"] = ("achieved = algorithmic bytes of both steps / launch time: an effective rate against the HBM peak, not HBM traffic - "
+                         "the second step reads what the first wrote from the XCD's L2 or the Infinity Cache")
+        return B, r
+
+    def workload_name(storage, n):
+        if a.config == "tgv" and n[0] == n[1] == n[2] // world:
+            return "taylor_green_%d^3_per_gpu_d3q19_srt_%s" % (n[0], storage.lower())
+        return "%s_%s_per_gpu_d3q%d_%s_%s%s" % (cfg["label"], "%dx%dx%d" % (n[0], n[1], n[2] // world), cfg["Q"], cfg["collision"].lower(), storage.lower(),
+                                                 "".join("_" + f.lower() for f in cfg["features"]))
+
+    N, seconds, per_rank, ms_events, geometry, overlap = measure(a.storage)
+    # the metric is quoted for FP32 and FP16S DDFs: the default run measures the same lattice again with FP16S storage
+    second = measure("FP16S") if (a.config == "tgv" and a.storage == "FP32" and not a.no_fp16s) else None
+    ranks = None
+    if world > 1:  # where every rank sat
+        props = torch.cuda.get_device_properties(device)
+        mine = {"rank": rank, "local_rank": local_rank, "device": device, "name": props.name, "host": socket.gethostname(), "pid": os.getpid(),
+                "pci_bus_id": "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0)),
+                "uuid": str(getattr(props, "uuid", "")), "visible_devices": os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")}
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine)
 
     cells_global = N[0] * N[1] * N[2]
     cells_rank = N[0] * N[1] * (N[2] // world)
     value = cells_global * a.steps / seconds / 1e6
-    mask_bits = feature_mask(cfg["features"])
-    B = lib.lbmhip_bandwidth_bytes_per_cell(cfg["Q"], STORAGE[a.storage], mask_bits)
     if rank == 0:
-        geometry = {}
-        check(lib.lbmhip_get_tuning(lbm.ops.dom.h, b"fused", C.byref(fused)))  # of the timed call
-        keys = ("pair_lag", "pair_blocks_per_cu") if fused.value else ("tuned", "cells_per_thread", "cells_together", "blocks_per_cu", "block", "jit")
-        for key in keys:
-            v = C.c_int(); check(lib.lbmhip_get_tuning(lbm.ops.dom.h, key.encode(), C.byref(v))); geometry[key] = v.value
-        steps_per_launch = 2 if fused.value else 1
-        geometry["steps_per_launch"] = steps_per_launch
-        per_gpu = "%dx%dx%d" % (N[0], N[1], N[2] // world)
-        if a.config == "tgv" and N[0] == N[1] == N[2] // world:
-            workload = "taylor_green_%d^3_per_gpu_d3q19_srt_%s" % (N[0], a.storage.lower())
-        else:
-            workload = "%s_%s_per_gpu_d3q%d_%s_%s%s" % (cfg["label"], per_gpu, cfg["Q"], cfg["collision"].lower(), a.storage.lower(),
-                                                         "".join("_" + f.lower() for f in cfg["features"]))
-        # N=1: the timed region is a.steps / steps_per_launch launches of one kernel (an odd a.steps ends with one single-step launch)
-        kernel_ms = ms_events.value / a.steps * steps_per_launch   # per launch
-        achieved = B * cells_rank * steps_per_launch / (kernel_ms * 1e-3) / 1e9
-        traffic, traffic_source = measured_traffic(workload + ("_2steps" if fused.value else "")) if world == 1 else (None, None)
+        workload = workload_name(a.storage, N)
+        B, roof = roofline(a.storage, N, ms_events, geometry, workload)
         headline = a.config == "tgv" and a.storage == "FP32" and N[0] == N[1] == 512 and N[2] == 512 * world
         out = {
             "metric": "MLUPs/s", "value": round(value, 1), "unit": "MLUPs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -251,15 +287,19 @@ def main():
             "vs_baseline": round(value / PUBLISHED_MLUPS[world], 4) if (headline and world in PUBLISHED_MLUPS) else None,
             "dtype": "f32" if a.storage == "FP32" else "f32 arithmetic, %s DDF storage" % a.storage.lower(), "data": "synthetic",
             "config": {"workload": workload, "lattice": list(N), "velocity_set": "D3Q%d" % cfg["Q"], "collision": cfg["collision"], "extensions": list(cfg["features"]),
-                       "ddf_storage": a.storage, "decomposition": "z-slabs x%d" % world, "bytes_per_cell_step": B, "halo_overlap": bool(lbm.overlap),
+                       "ddf_storage": a.storage, "decomposition": "z-slabs x%d" % world, "bytes_per_cell_step": B, "halo_overlap": overlap,
                        "backend": ("rccl" if a.backend == "nccl" else a.backend) if world > 1 else None, "lattice_reduced_to_fit": bool(reduced),
-                       "launch_geometry": geometry, "tuning_steps_untimed": "up to %d, until the geometry search finished" % TUNE_STEPS},
+                       "launch_geometry": geometry, "tuning_steps_untimed": "up to %d, until the geometry search finished" % TUNE_STEPS, "ranks": ranks},
             "timed_region_s": round(seconds, 4),
             "per_rank_mlups": [round(cells_rank * a.steps / s / 1e6, 1) for s in per_rank],
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "traffic_source": traffic_source, "kernel": "stream_collide, two steps per launch (k_collide_pair)" if fused.value else "stream_collide",
-                         "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": B * cells_rank * steps_per_launch},
+            "roofline": roof,
         }
+        if second:
+            n2, seconds2, per_rank2, ms2, geometry2, _ = second
+            B2, roof2 = roofline("FP16S", n2, ms2, geometry2, workload_name("FP16S", n2))
+            out["fp16s"] = {"value": round(cells_global * a.steps / seconds2 / 1e6, 1), "unit": "MLUPs/s", "ms_per_step": round(seconds2 / a.steps * 1e3, 4),
+                            "dtype": "f32 arithmetic, fp16s DDF storage", "bytes_per_cell_step": B2, "timed_region_s": round(seconds2, 4),
+                            "per_rank_mlups": [round(cells_rank * a.steps / s / 1e6, 1) for s in per_rank2], "roofline": roof2, "launch_geometry": geometry2}
         if seconds < SHORT_REGION_S:
             out["short_timed_region"] = True
             print("bench.py: the timed region lasted %.3f s; --steps %d or more gives at least %.1f s" % (
@@ -271,7 +311,6 @@ def main():
             if cavity:
                 out["cpu_baseline_cavity128"] = cavity
         print(json.dumps(out), flush=True)
-    lbm.close()
     if world > 1:
         dist.destroy_process_group()
 

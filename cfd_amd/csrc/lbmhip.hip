@@ -699,20 +699,20 @@ int lbmhip_stream_collide(lbmhip_domain* d, uint64_t t, float fx, float fy, floa
 	NEED(d, "null domain");
 	return launch_collide_planes(d, t, fx, fy, fz, 0u, d->cfg.Nz, false);
 }
-// Two steps per launch: when does it apply, and with which geometry?  The lattice must be one periodic domain (a step
-// between two exchanges cannot be paired), without UPDATE_FIELDS, with a compiled k_collide_pair instance; and the planes
-// that lie between the two steps (lag + 4 of them) must fit the Infinity Cache with room to spare, else the second step
-// reads from HBM like a launch of its own and only the waiting is left.  lag = 2 + the planes the resident workgroups
-// cover, rounded up: the second step then asks for planes whose workgroups have left.  Measured at 512^3
-// D3Q19 FP32 (20 MB planes, tools/fused_sweep.py): no residency cap and lag 4 (79.8 % of 8 TB/s against 68.4 % with a launch
-// per step; lag 3: 70 %, lag 5: 77 %, lag 8: 65 %).
-// Automatic mode (fuse = -1) pairs only where it was measured to pay (tools/fused_sweep.py, MI355X): plain D3Q19 SRT on
-// planes of at least 512 x 512 cells made of whole 256-lane chunks - 512^3 FP32 41 400 against 35 700 MLUPs/s (79.2 against
-// 68.3 % of 8 TB/s), FP16S 75 200 against 67 200 (72.5 against 64.6 %).  Smaller planes are a fraction of what is resident on
-// the chip, the lag in planes grows and the best residency cap changes (256^3: 73 against 69 % with at most 6 workgroups
-// per CU, 67 % without a cap; 384^3, whose rows end in a half-empty chunk: 63 against 65 %); the TRT + subgrid channel
-// kernel (132 registers, 3 workgroups per CU) loses 5 %.  fuse = 1 pairs whenever it can.
-static const uint64_t kPairWindowBytes = 200ull<<20;
+// Two steps per launch: when does it apply, in which form and with which geometry?  The lattice must be one domain that is not
+// split in x or y (the whole periodic lattice, or the inner planes of a z-slab between two halo exchanges), without
+// UPDATE_FIELDS, with compiled instances (collide_pairs.hip).
+//   k_collide_band (fuse = 2, and what automatic mode uses): band by band on each XCD, lbm_kernels.hpp.  Measured with
+//   tools/fused_sweep.py on MI355X, D3Q19 SRT without extensions, MLUPs/s against one launch per step and against
+//   k_collide_pair: 512^3 FP32 46 300 / 35 700 / 41 400 (88.5 / 68.3 / 79.2 % of 8 TB/s), FP16S 79 900 / 67 500 / 74 400,
+//   FP16C 73 600 / 66 700 / 70 600; 256^3 FP32 43 700 / 36 000 / 37 100; 384^3 39 100 / 34 300 / 35 100; 1024^3 42 000 /
+//   34 300 / 33 600, FP16S 78 500 / 71 500 / 74 500.  The planes may be of any size: the lines between the two steps are those of
+//   a band.  Best with 32 tasks per plane of a band, no residency cap and the lag that lets step t's workgroups leave before
+//   step t+1 asks for them (6 planes at 32 tasks); shorter lags wait, caps cost more bandwidth than the L2 hits return.
+//   The TRT + subgrid channel kernel (132 registers, 3 workgroups per CU) loses to single launches in either form (65 against
+//   72 %), so automatic mode pairs plain D3Q19 SRT only; fuse = 1 or 2 pairs whatever has an instance.
+//   k_collide_pair (fuse = 1): any placement of the workgroups, step t+1 reads from the Infinity Cache, so lag + 4 planes must
+//   fit it with room to spare (512^3 FP32: lag 4 and no cap 79.8 %, lag 3 70 %, lag 5 77 %, lag 8 65 %).
 // mode 1: k_collide_pair (step t+1 reads from the Infinity Cache, any placement of the workgroups); mode 2: k_collide_band (from the L2 of
 // the XCD, band by band, + k_collide_seam)
 struct PairPlan { PairKernels k; int mode; uint32_t lag, xchunks, block; int blocks_per_cu; uint32_t block_rows, R, bands; };
@@ -732,11 +732,14 @@ static bool pair_plan(const lbmhip_domain* d, PairPlan* plan) {
 	// band by band on each XCD: blocks of ceil(Ny/8) rows, at least 4 rows each
 	plan->block_rows = (d->cfg.Ny+7u)/8u;
 	const bool band_possible = plan->block_rows >= 4u && d->cfg.Nz >= 8u;
-	plan->mode = (d->fuse == 2 && band_possible) ? 2 : 1;
+	const bool plain = d->cfg.velocity_set == 19u && d->cfg.collision == LBMHIP_SRT && d->cfg.features == 0u;
+	if (d->fuse < 0 && !(band_possible && plain && (uint64_t)d->cfg.Nx*d->cfg.Ny >= 256ull*256ull)) return false; // automatic mode: where it was measured to pay
+	plan->mode = (d->fuse != 1 && band_possible) ? 2 : 1;
 	if (plan->mode == 2) {
-		plan->R = std::max(2u, d->band_rows > 0 ? std::min((uint32_t)d->band_rows, plan->block_rows) : std::min(16u, plan->block_rows));
+		// 32 tasks per plane of a band measured best at 512^3 (FP32: 16 rows of two chunks, 16-bit DDFs: 32 rows of one), flat from 16 to 64
+		plan->R = std::max(2u, std::min(d->band_rows > 0 ? (uint32_t)d->band_rows : std::max(2u, 32u/plan->xchunks), plan->block_rows));
 		plan->bands = (plan->block_rows+plan->R-1u)/plan->R;
-		plan->blocks_per_cu = d->band_blocks_per_cu >= 0 ? d->band_blocks_per_cu : 4;
+		plan->blocks_per_cu = d->band_blocks_per_cu >= 0 ? d->band_blocks_per_cu : 0; // every residency cap lost at 512^3 (FP32: 88.5 % of 8 TB/s without, 86.5 % with 6, 82 % with 5 workgroups per CU)
 		// the workgroups of an XCD that are resident together cover `resident` tasks of its queue; step t+1 follows far enough behind
 		// step t that the workgroups it waits for have left (each plane of a band is R*xchunks tasks of each step)
 		const uint32_t resident = (uint32_t)(d->compute_units/8)*(uint32_t)(plan->blocks_per_cu > 0 ? std::min(plan->blocks_per_cu*256/(int)plan->block, per_cu_max) : per_cu_max);
@@ -749,9 +752,6 @@ static bool pair_plan(const lbmhip_domain* d, PairPlan* plan) {
 	const uint64_t resident = (uint64_t)d->compute_units*(uint64_t)(plan->blocks_per_cu > 0 ? std::min(plan->blocks_per_cu*256/(int)plan->block, per_cu_max) : per_cu_max);
 	plan->lag = d->pair_lag ? (uint32_t)d->pair_lag : std::max(3u, 2u+(uint32_t)((resident+per_plane-1u)/per_plane));
 	if (d->cfg.Nz < plan->lag+4u) return false;
-	const uint64_t plane_bytes = (uint64_t)d->cfg.Nx*d->cfg.Ny*d->cfg.velocity_set*d->fpxx_bytes;
-	if (d->fuse < 0 && ((uint64_t)(plan->lag+4u)*plane_bytes > kPairWindowBytes || (uint64_t)d->cfg.Nx*d->cfg.Ny < 512ull*512ull || lanes_per_row%256u != 0u ||
-	                    d->cfg.velocity_set != 19u || d->cfg.collision != LBMHIP_SRT || d->cfg.features != 0u)) return false;
 	return true;
 }
 static int pairs_steps(const lbmhip_domain* d) {

@@ -172,6 +172,7 @@ class HipSlabOps(SlabOps):
     def sync(self):
         self.compute.synchronize()
         self.comm.synchronize()
+        L.check(self.lib.lbmhip_sync(self.dom.h))  # also the library's own look at what its two-step launches reported
 
 
 class DistributedLBM:

@@ -260,3 +260,8 @@ def test_bench_launches_its_own_ranks(gpu, extra):
     assert r["n_gpus"] == 2 and r["value"] > 0 and len(r["per_rank_mlups"]) == 2
     assert r["config"]["decomposition"] == "z-slabs x2" and r["config"]["launch_geometry"]["cells_per_thread"] >= 0
     assert r["roofline"]["frac"] > 0
+    ranks = r["config"]["ranks"]  # where every rank sat
+    assert len(ranks) == 2 and sorted(k["rank"] for k in ranks) == [0, 1] and all(k["device"] == 0 and k["pci_bus_id"] for k in ranks)
+    assert ("fp16s" in r) == (not extra)  # the default configuration is measured with FP16S DDFs as well
+    if not extra:
+        assert r["fp16s"]["value"] > 0 and r["fp16s"]["roofline"]["frac"] > 0 and len(r["fp16s"]["per_rank_mlups"]) == 2

@@ -125,6 +125,23 @@ def test_banded_steps_equal_the_oracle(gpu, kw, setup):
         a.close()
 
 
+@pytest.mark.parametrize("storage", ["FP32", "FP16S"])
+def test_automatic_pairing_equals_the_oracle(gpu, storage):
+    """Nothing set by hand: planes of 512 x 512 cells pair automatically, with the automatic band height and lag, and give the oracle's bits."""
+    kw = dict(N=(512, 512, 12), nu=0.01, storage=storage)
+    a = cfd_amd.LBM(**kw); b = H.OracleLBM(**kw)
+    try:
+        a.set_tuning("autotune", 0)
+        setups.taylor_green(a); setups.taylor_green(b)
+        a.run(6); b.run(6, threads=16)
+        assert fused_flag(a) == 2 and tuning(a, "fuse") == -1 and tuning(a, "band_given_up") == 0
+        assert np.array_equal(bits(a.domains[0].download_fi()), bits(b.domains[0].fi)), "DDFs differ from the oracle"
+        a.read_from_device(); b.read_from_device()
+        assert np.array_equal(bits(a.rho), bits(b.rho)) and np.array_equal(bits(a.u), bits(b.u))
+    finally:
+        a.close()
+
+
 @pytest.mark.parametrize("kw,setup", [(CHANNEL, setups.channel), (HALF_S, setups.taylor_green), (HALF_C, setups.taylor_green)])
 def test_paired_steps_equal_the_oracle(gpu, kw, setup):
     a = cfd_amd.LBM(**kw); b = H.OracleLBM(**kw)
@@ -157,19 +174,22 @@ def test_what_is_never_paired(gpu):
             a.close()
 
 
-def test_large_planes_pair_only_on_request(gpu):
-    """Automatic mode leaves lattices alone whose planes between the two steps would not fit the cache."""
-    kw = dict(N=(2048, 1024, 16), nu=0.02)  # 160 MB planes
-    a = cfd_amd.LBM(**kw)
+def test_large_planes_pair_band_by_band(gpu):
+    """Planes far larger than any cache (160 MB) pair automatically - band by band, the lines between the two steps are those of a
+    band - and k_collide_pair, whose second step reads whole planes back, runs on request only; both leave the bits of single launches."""
+    kw = dict(N=(2048, 1024, 16), nu=0.02)
+    a = cfd_amd.LBM(**kw); b = cfd_amd.LBM(**kw)
     try:
-        setups.taylor_green(a)
-        a.run(2)
-        assert fused_flag(a) == 0
+        b.set_tuning("fuse", 0)
+        setups.taylor_green(a); setups.taylor_green(b)
+        a.run(2); b.run(2)
+        assert fused_flag(a) == 2 and fused_flag(b) == 0
         a.set_tuning("fuse", 1)
-        a.run(2)
+        a.run(2); b.run(2)
         assert fused_flag(a) == 1
+        assert np.array_equal(bits(a.domains[0].download_fi()), bits(b.domains[0].download_fi()))
     finally:
-        a.close()
+        a.close(); b.close()
 
 
 def test_pair_planes_entry_point(gpu):
@@ -224,8 +244,8 @@ def test_slabs_of_one_process_pair_their_steps(gpu):
 
 @pytest.mark.parametrize("storage", ["FP32", "FP16S"])
 def test_headline_lattice_paired_equals_single_launches(gpu, storage):
-    """512^3, the lattice of the headline figure, where pairing is automatic: 200 steps with two steps per launch (100 launches of
-    a million workgroups each) leave the bits of 200 single launches in every DDF stream."""
+    """512^3, the lattice of the headline figure, where pairing is automatic (band by band on each XCD): 200 steps with two steps per
+    launch (100 launches of a million workgroups each) leave the bits of 200 single launches in every DDF stream."""
     import zlib
     crcs = {}
     for fuse in (-1, 0):
@@ -233,7 +253,7 @@ def test_headline_lattice_paired_equals_single_launches(gpu, storage):
             lbm.set_tuning("fuse", fuse); lbm.set_tuning("autotune", 0)
             setups.taylor_green(lbm)
             lbm.run(200)
-            assert fused_flag(lbm) == (1 if fuse else 0)
+            assert fused_flag(lbm) == (2 if fuse else 0)
             fi = lbm.domains[0].download_fi()
             n = 512 ** 3
             crcs[fuse] = [zlib.crc32(fi[i * n:(i + 1) * n]) for i in range(19)]
