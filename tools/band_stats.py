@@ -2,9 +2,10 @@
 
 usage: LBMHIP_LIB=$PWD/tools/ab/lbm_exp32.so LBMHIP_BAND_STATS=1 python tools/band_stats.py [n] [rows] [cap] [lags...]
 """
+import os
 import sys
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import cfd_amd
 from cfd_amd import setups
 
