@@ -218,6 +218,7 @@ class DistributedLBM:
         self.next = (self.rank + 1) % self.world
         self.prev = (self.rank - 1) % self.world
         self._host_staging = None
+        self._packed_t = None  # time step of DDF faces that are packed but not yet exchanged (_do_two_time_steps)
 
     def get_N(self):
         return self.N[0] * self.N[1] * self.N[2]
@@ -257,6 +258,13 @@ class DistributedLBM:
         self.ops.pack(what, self.t)
         self._exchange(self.ops.halo_bytes(what))
         self.ops.unpack(what, self.t)
+
+    def _finish_packed_exchange(self):
+        """The exchange whose faces _do_two_time_steps packed and left for later (on the communication stream of an overlapped run)."""
+        if self._packed_t is not None:
+            t, self._packed_t = self._packed_t, None
+            self._exchange(self.ops.halo_bytes("fi"))
+            self.ops.unpack("fi", t)
 
     # ---- LBM::initialize (lbm.cpp:1354-1409)
     def initialize(self):
@@ -325,18 +333,21 @@ class DistributedLBM:
             self.t_last_update_fields = self.t
 
     def _do_two_time_steps(self):
-        """Steps t and t+1 of a slab with one exchange hidden and one exposed instead of two hidden ones, so that the engine can
-        run the inner planes of both steps in one launch (lbmhip_stream_collide_pair_planes):
-          step t on the planes next to the halos, exchange t                          (communication stream)
-          step t on the planes 2 .. Lz-3 and step t+1 on the planes 4 .. Lz-5        (compute stream, beside the exchange)
-          step t+1 on the planes 1..3 and Lz-4..Lz-2, which need the halos of step t  (compute stream, after the exchange)
-          exchange t+1
-        A cell of step t+1 in plane p depends on step t in the planes p-2 .. p+2, so the planes 4 .. Lz-5 need nothing from a
-        halo; every cell still sees exactly the values of the step before (same bits as two calls of _do_time_step)."""
+        """Steps t and t+1 of a slab, the inner planes of both in one launch (lbmhip_stream_collide_pair_planes), both exchanges hidden:
+          [exchange t-1, packed by the call before]; step t on the planes next to the halos, exchange t      (communication stream)
+          step t on the planes 2 .. Lz-3 and step t+1 on the planes 4 .. Lz-5                                (compute stream, beside them)
+          step t+1 on the planes 1..3 and Lz-4..Lz-2, which need the halos of step t; pack the faces of t+1  (compute stream, after the join)
+        The exchange of step t+1 is left to the next call (or to run(), after the last pair), where it runs beside the next inner
+        launch: step t+2 on the planes 2 .. Lz-3 owns no slot in a halo plane and none that the unpack writes - those belong to the
+        cells of the planes 1 and Lz-2, whose step t+2 follows the unpack on the communication stream.
+        A cell of step t+1 in plane p depends on step t in the planes p-1 .. p+1 (the entry point keeps two planes of distance),
+        so the planes 4 .. Lz-5 need nothing from a halo; every cell still sees exactly the values of the step before (same bits as
+        two calls of _do_time_step)."""
         Lz = self.local[2]
         o = self.ops
         o.fork()
         try:
+            self._finish_packed_exchange()
             o.collide_planes(self.t, self.f, 1, 2)
             o.collide_planes(self.t, self.f, Lz - 2, Lz - 1)
             self._communicate("fi")
@@ -347,10 +358,21 @@ class DistributedLBM:
         self.t += 1
         o.collide_planes(self.t, self.f, 1, 4)
         o.collide_planes(self.t, self.f, Lz - 4, Lz - 1)
-        self._communicate("fi")
+        o.pack("fi", self.t)
+        self._packed_t = self.t
         self.t += 1
         if self.update_fields_ext:
             self.t_last_update_fields = self.t
+
+    def _flush_packed_exchange(self):
+        if self._packed_t is not None:
+            o = self.ops
+            o.fork()
+            try:
+                self._finish_packed_exchange()
+            finally:
+                o.end_fork()
+            o.join()
 
     def run(self, steps):
         with self.ops.scope():
@@ -360,6 +382,7 @@ class DistributedLBM:
             if self.world > 1 and self.overlap and self.pair_steps and self.local[2] >= 12 and int(steps) >= 2 and self.ops.pairs_steps():
                 for _ in range(int(steps) // 2):
                     self._do_two_time_steps()
+                self._flush_packed_exchange()
                 steps = int(steps) % 2
             if self.world <= 1 and int(steps) > 0:  # no exchange between the steps: the engine may pair them (lbmhip_stream_collide_steps)
                 self.ops.collide_steps(self.t, self.f, int(steps))

@@ -302,6 +302,20 @@ void LBM::communicate(const int what) {
 		for (LBM_Domain* d : lbm_domain) check(lbmhip_halo_unpack(d->handle, what, axis, d->get_t()));
 	}
 }
+// z-slabs: the DDF faces that do_two_time_steps packed at time step packed_t and left for later
+void LBM::finish_packed_exchange() {
+	if (!packed_pending) return;
+	packed_pending = false;
+	check(lbmhip_halo_exchange_local(handles.data(), (uint)handles.size(), LBMHIP_HALO_FI, 2));
+	for (LBM_Domain* d : lbm_domain) check(lbmhip_halo_unpack(d->handle, LBMHIP_HALO_FI, 2, packed_t));
+}
+void LBM::flush_packed_exchange() {
+	if (!packed_pending) return;
+	for (LBM_Domain* d : lbm_domain) check(lbmhip_comm_begin(d->handle));
+	finish_packed_exchange();
+	for (LBM_Domain* d : lbm_domain) check(lbmhip_comm_end(d->handle));
+	for (LBM_Domain* d : lbm_domain) check(lbmhip_comm_join(d->handle));
+}
 
 void LBM::initialize() { // lbm.cpp:1354-1409
 #ifndef BENCHMARK
@@ -353,15 +367,20 @@ bool LBM::pairs_slab_steps() const {
 // two calls of do_time_step.
 void LBM::do_two_time_steps() {
 	const uint Lz = lbm_domain[0]->get_Nz();
-	for (LBM_Domain* d : lbm_domain) { d->enqueue_stream_collide_planes(1u, 2u); d->enqueue_stream_collide_planes(Lz-2u, Lz-1u); }
+	// communication streams: the exchange the call before left packed, then step t next to the halos and its exchange
 	for (LBM_Domain* d : lbm_domain) check(lbmhip_comm_begin(d->handle));
+	finish_packed_exchange();
+	for (LBM_Domain* d : lbm_domain) { d->enqueue_stream_collide_planes(1u, 2u); d->enqueue_stream_collide_planes(Lz-2u, Lz-1u); }
 	communicate(LBMHIP_HALO_FI);
 	for (LBM_Domain* d : lbm_domain) check(lbmhip_comm_end(d->handle));
+	// compute streams, beside them: step t on 2 .. Lz-3 and step t+1 on 4 .. Lz-5 in one launch
 	for (LBM_Domain* d : lbm_domain) d->enqueue_stream_collide_pair_planes(2u, Lz-2u);
 	for (LBM_Domain* d : lbm_domain) check(lbmhip_comm_join(d->handle));
 	for (LBM_Domain* d : lbm_domain) d->increment_time_step();
 	for (LBM_Domain* d : lbm_domain) { d->enqueue_stream_collide_planes(1u, 4u); d->enqueue_stream_collide_planes(Lz-4u, Lz-1u); }
-	communicate(LBMHIP_HALO_FI);
+	// the faces of step t+1 are packed here; their exchange runs beside the next pair's inner launch (or at the end of run())
+	for (LBM_Domain* d : lbm_domain) check(lbmhip_halo_pack(d->handle, LBMHIP_HALO_FI, 2, d->get_t()));
+	packed_t = lbm_domain[0]->get_t(); packed_pending = true;
 	for (LBM_Domain* d : lbm_domain) d->increment_time_step();
 }
 
@@ -380,6 +399,7 @@ void LBM::run(const ulong steps, const ulong total_steps) { // lbm.cpp:1461-1489
 		} else if (n >= 2ull && pairs_slab_steps()) {
 			ulong k = 0ull;
 			for (; k+1ull < n; k += 2ull) do_two_time_steps();
+			flush_packed_exchange();
 			for (; k < n; k++) do_time_step();
 		} else for (ulong k = 0ull; k < n; k++) do_time_step();
 		for (LBM_Domain* d : lbm_domain) d->finish_queue();

@@ -109,6 +109,9 @@ class LBM {
 	void initialize();
 	void do_time_step();
 	void do_two_time_steps(); // z-slabs: two steps with the inner planes of both in one launch per domain
+	void finish_packed_exchange(); // the exchange of the DDF faces do_two_time_steps left packed, on the streams that are current
+	void flush_packed_exchange();  // the same on the communication streams, joined
+	bool packed_pending = false; ulong packed_t = 0ull;
 	bool pairs_slab_steps() const;
 	void communicate(const int what);
 public:

@@ -48,11 +48,20 @@ struct Slab {
 		check(lbmhip_comm_join(dom));
 		t++;
 	}
-	// Steps t and t+1 with the inner planes of both in one launch (lbmhip_stream_collide_pair_planes): the exchange of step t
-	// runs beside that launch, the six planes near the halos take step t+1 afterwards, then the exchange of step t+1.
+	// Steps t and t+1 with the inner planes of both in one launch (lbmhip_stream_collide_pair_planes).  Both exchanges run beside an
+	// inner launch: that of step t beside this call's, that of step t+1 - packed here - beside the next call's (step t+2 on the planes
+	// 2 .. Lz-3 owns no slot that the unpack writes; the planes 1 and Lz-2 follow the unpack on the second stream).
+	bool packed = false; uint64_t packed_t = 0;
+	void finish_packed() {
+		if (!packed) return;
+		packed = false;
+		check(lbmhip_halo_exchange_rccl(dom, comm, LBMHIP_HALO_FI, 2, minus, plus));
+		check(lbmhip_halo_unpack(dom, LBMHIP_HALO_FI, 2, packed_t));
+	}
 	bool pairs() const { int v = 0; check(lbmhip_get_tuning(dom, "pairs_steps", &v)); return split && Lz >= 12u && v != 0; }
 	void two_steps() {
 		check(lbmhip_comm_begin(dom));
+		finish_packed();
 		check(lbmhip_stream_collide_planes(dom, t, 0.0f, 0.0f, 0.0f, 1u, 2u));
 		check(lbmhip_stream_collide_planes(dom, t, 0.0f, 0.0f, 0.0f, Lz-2u, Lz-1u));
 		communicate(LBMHIP_HALO_FI);
@@ -62,14 +71,23 @@ struct Slab {
 		t++;
 		check(lbmhip_stream_collide_planes(dom, t, 0.0f, 0.0f, 0.0f, 1u, 4u));
 		check(lbmhip_stream_collide_planes(dom, t, 0.0f, 0.0f, 0.0f, Lz-4u, Lz-1u));
-		communicate(LBMHIP_HALO_FI);
+		check(lbmhip_halo_pack(dom, LBMHIP_HALO_FI, 2, t));
+		packed = true; packed_t = t;
 		t++;
+	}
+	void flush_packed() {
+		if (!packed) return;
+		check(lbmhip_comm_begin(dom));
+		finish_packed();
+		check(lbmhip_comm_end(dom));
+		check(lbmhip_comm_join(dom));
 	}
 	void run(const int steps) { // pairs of steps where the library runs them in one launch, single steps otherwise
 		const bool paired = pairs();
 		for (int k = 0; k < steps; ) {
-			if (paired && k+1 < steps) { two_steps(); k += 2; } else { step(); k++; }
+			if (paired && k+1 < steps) { two_steps(); k += 2; } else { flush_packed(); step(); k++; }
 		}
+		flush_packed();
 	}
 };
 

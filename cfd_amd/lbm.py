@@ -185,6 +185,7 @@ class LBM:
             self.close()
             raise
         self._handles = (C.c_void_p * nd)(*[dom.h for dom in self.domains])
+        self._packed_t = None  # time step of DDF faces that are packed but not yet exchanged (_do_two_time_steps)
         Nx, Ny, Nz = self.N
         self.rho = np.ones((Nz, Ny, Nx), dtype=np.float32)
         self.u = np.zeros((3, Nz, Ny, Nx), dtype=np.float32)
@@ -388,19 +389,44 @@ class LBM:
                 return False
         return True
 
+    def _finish_packed_exchange(self):
+        """The exchange of the DDF faces _do_two_time_steps left packed (on whichever streams are current)."""
+        if self._packed_t is None:
+            return
+        t, self._packed_t = self._packed_t, None
+        check(self._L.lbmhip_halo_exchange_local(self._handles, len(self.domains), HALO_FI, 2))
+        for dom in self.domains:
+            check(self._L.lbmhip_halo_unpack(dom.h, HALO_FI, 2, C.c_uint64(t)))
+
+    def _flush_packed_exchange(self):
+        if self._packed_t is None:
+            return
+        L = self._L
+        for dom in self.domains:
+            check(L.lbmhip_comm_begin(dom.h))
+        self._finish_packed_exchange()
+        for dom in self.domains:
+            check(L.lbmhip_comm_end(dom.h))
+        for dom in self.domains:
+            check(L.lbmhip_comm_join(dom.h))
+
     def _do_two_time_steps(self):
-        """Two steps of z-slabs with the inner planes of both in one launch per domain (lbmhip_stream_collide_pair_planes): step t next to
-        the halos and its exchange beside that launch, then step t+1 on the six planes near the halos and its exchange.  Same bits as
-        two calls of do_time_step (a cell of step t+1 in plane p depends on step t in the planes p-2 .. p+2 only)."""
+        """Two steps of z-slabs with the inner planes of both in one launch per domain (lbmhip_stream_collide_pair_planes), both
+        exchanges beside an inner launch: on the communication streams the exchange the call before left packed, step t next to the
+        halos and its exchange; beside them the inner launch; after the join step t+1 on the six planes near the halos, whose faces
+        are packed and left for the next call (or for run(), after the last pair).  Same bits as two calls of do_time_step (a cell
+        of step t+1 in plane p depends on step t in the planes p-1 .. p+1 only, and step t+2 on the planes 2 .. Lz-3 owns no slot that
+        the unpack of step t+1 writes)."""
         L = self._L
         Lz = self.local[2]
         fx, fy, fz = C.c_float(self.fx), C.c_float(self.fy), C.c_float(self.fz)
         t = C.c_uint64(self.t)
         for dom in self.domains:
+            check(L.lbmhip_comm_begin(dom.h))
+        self._finish_packed_exchange()
+        for dom in self.domains:
             check(L.lbmhip_stream_collide_planes(dom.h, t, fx, fy, fz, 1, 2))
             check(L.lbmhip_stream_collide_planes(dom.h, t, fx, fy, fz, Lz - 2, Lz - 1))
-        for dom in self.domains:
-            check(L.lbmhip_comm_begin(dom.h))
         self._communicate(HALO_FI)
         for dom in self.domains:
             check(L.lbmhip_comm_end(dom.h))
@@ -413,7 +439,9 @@ class LBM:
         for dom in self.domains:
             check(L.lbmhip_stream_collide_planes(dom.h, t, fx, fy, fz, 1, 4))
             check(L.lbmhip_stream_collide_planes(dom.h, t, fx, fy, fz, Lz - 4, Lz - 1))
-        self._communicate(HALO_FI)
+        for dom in self.domains:
+            check(L.lbmhip_halo_pack(dom.h, HALO_FI, 2, t))
+        self._packed_t = self.t
         self.t += 1
         if self.update_fields_ext:
             self.t_last_update_fields = self.t
@@ -424,6 +452,7 @@ class LBM:
         if int(steps) >= 2 and self._pairs_slab_steps():
             for _ in range(int(steps) // 2):
                 self._do_two_time_steps()
+            self._flush_packed_exchange()
             steps = int(steps) % 2
         if len(self.domains) == 1 and int(steps) > 0:  # no exchange between the steps: the library may run them two per launch
             check(self._L.lbmhip_stream_collide_steps(self.domains[0].h, C.c_uint64(self.t), C.c_uint32(int(steps)), C.c_float(self.fx), C.c_float(self.fy), C.c_float(self.fz)))

@@ -59,7 +59,7 @@ def test_slab_exchange_matches_single_process(tmp_path, world, overlap, setup):
     from cfd_amd import setups
     from oracle import harness as H
     kw = dict(N=(16, 12, 12 * world), nu=0.02, Q=19, storage="FP32", collision="SRT", features=("VOLUME_FORCE", "SUBGRID"), f=(1e-4, 0.0, 0.0))
-    steps = 13  # six pairs of steps and a single one
+    steps = 15  # seven pairs of steps (every second exchange packed by one pair and finished beside the next) and a single one
     mp.spawn(_worker, args=(world, _free_port(), kw, setup, steps, overlap, str(tmp_path)), nprocs=world, join=True)
     ref = H.OracleLBM(kw["N"], kw["nu"], D=(1, 1, world), Q=19, features=kw["features"], f=kw["f"])
     setups.channel(ref)
