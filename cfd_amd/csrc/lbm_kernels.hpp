@@ -503,7 +503,10 @@ __global__ __launch_bounds__(256, (P == 2 && V == 2 ? 3 : 1)) void k_collide_wid
 //   Every step-t workgroup counts itself done (a counter per plane and shard; the last arriver of a shard reports to the
 //   plane's word), every step-t+1 workgroup waits until the five planes p-2..p+2 have all their shards reported.  With
 //   lag >= 3 a workgroup only ever waits for workgroups with smaller grid indices, which have been dispatched before it.
-//   The wait is bounded: when it runs out the workgroup sets *error and goes on (the host then reports the failure).
+//   The wait is bounded: when it runs out the workgroup raises *error, writes its task to the redo list and computes nothing;
+//   every other wait that finds a plane unfinished looks at *error and gives up too.  k_collide_seam, launched behind, runs
+//   the tasks of the list (step t is complete by then, nothing in the launch depends on step t+1): the lattice is right in
+//   every case, only time is lost, and the host turns the pairing off when it finds *error set.
 //   Visibility between workgroups of the launch (per-XCD L2s are not coherent, a CU's L1 is never refreshed): step t
 //   stores its DDFs written through at agent scope, drains them (s_waitcnt vmcnt(0) in every wave, then a workgroup
 //   barrier) before one lane counts the workgroup done with an agent-scope atomic; step t+1 polls with agent-scope loads
@@ -516,7 +519,9 @@ struct PairArgs {
 	uint32_t* plane_done; // PAIR_REPLICAS arrays, replica_stride words apart, of Nz words: shards of the plane that have reported (zeroed before the launch)
 	uint32_t replica_stride;
 	uint32_t* shard_done; // Nz*PAIR_SHARDS counters, 64 bytes apart (zeroed before the launch)
-	uint32_t* error;      // set to 1 by a wait that ran out
+	uint32_t* error;      // raised by a wait that ran out (zeroed before the launch)
+	uint32_t* redo_count; // tasks of step t+1 given up (zeroed before the launch)
+	uint64_t* redo;       // their (z*Ny+y)*xchunks+chunk, for k_collide_seam
 	uint32_t lag;         // >= 3
 	uint32_t spin_limit;  // polls before a wait gives up
 	// Step t runs on the planes first1 .. first1+count1-1, step t+1 on first2 .. first2+count2-1 (taken modulo Nz).  The whole
@@ -531,6 +536,7 @@ constexpr uint32_t PAIR_SHARDS = 8u, PAIR_SHARD_STRIDE = 16u, PAIR_REPLICAS = 16
 // V = 1: the rows of k_collide; V = 2 (16-bit DDFs): the rows of k_collide_wide, P cells collided together.
 template <int Q, int ST, int COLL, int FEAT, int V = 1, int P = 1>
 __global__ __launch_bounds__(256, (P == 2 && V == 2 ? 3 : 1)) void k_collide_pair(const Args a, const PairArgs p) {
+	__shared__ uint32_t give_up;
 	const uint32_t Nz = a.Nz, task = blockIdx.y, per_plane = gridDim.x, in_plane = blockIdx.x;
 	// step t+1 on plane first2+j follows step t on plane first2+j+lag-1: `ahead` planes of step t come first, then the two
 	// alternate, then whichever step still has planes left finishes (gridDim.y = count1+count2)
@@ -563,16 +569,27 @@ __global__ __launch_bounds__(256, (P == 2 && V == 2 ? 3 : 1)) void k_collide_pai
 		if (threadIdx.x < 64u) {
 			const uint32_t lane = threadIdx.x, shards = per_plane < PAIR_SHARDS ? per_plane : PAIR_SHARDS; // shards without members never report
 			const uint32_t zz = (z+Nz-2u+(lane < 5u ? lane : 0u))%Nz;
-			const bool asked = (zz+Nz-p.first1)%Nz < p.count1; // planes outside this launch's step t were finished by earlier launches
+			const bool asked = lane < 5u && (zz+Nz-p.first1)%Nz < p.count1; // planes outside this launch's step t were finished by earlier launches
+			const uint32_t* const word = lane == 5u ? p.error : p.plane_done+(uint64_t)(in_plane%PAIR_REPLICAS)*p.replica_stride+zz;
+			bool failed = false;
 			for (uint32_t spins = 0u; ; spins++) {
-				bool ok = true;
-				if (lane < 5u && asked) ok = __hip_atomic_load(p.plane_done+(uint64_t)(in_plane%PAIR_REPLICAS)*p.replica_stride+zz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= shards;
-				if (__ballot(!ok) == 0ull) break;
-				if (spins >= p.spin_limit) { if (lane == 0u) __hip_atomic_store(p.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+				uint32_t v = 0u;
+				if (asked || (lane == 5u && spins > 0u)) v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // the error word only once a plane was found unfinished
+				if (__ballot(asked && v < shards) == 0ull) break;
+				if (__ballot(lane == 5u && v != 0u) != 0ull || spins >= p.spin_limit) {
+					if (lane == 0u) __hip_atomic_store(p.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					failed = true;
+					break;
+				}
 				if (spins < 2u) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(127); // a workgroup that is ahead of the first step asks rarely: its questions share the memory system with the work it waits for
+			}
+			if (lane == 0u) {
+				give_up = failed ? 1u : 0u;
+				if (failed) p.redo[__hip_atomic_fetch_add(p.redo_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = ((uint64_t)z*a.Ny+y)*a.xchunks+chunk;
 			}
 		}
 		__syncthreads();
+		if (give_up) return;
 		Args b = a;
 		b.odd = a.odd^1u;
 		if constexpr (V == 1) collide_row<Q, ST, COLL, FEAT, false, MEM_LOAD_COHERENT, true>(b, chunk, y, z, early);

@@ -51,10 +51,10 @@ struct lbmhip_domain {
 	void* mesh; uint64_t mesh_capacity; // triangle corners of the last voxelized mesh (grown on demand)
 	void* partial; // per-workgroup partial sums of the object_* reductions (kObjectSumBlocks float4)
 	float w;
-	// two time steps per launch (k_collide_pair): completion counters of the first step's workgroups, then one error word
+	// two time steps per launch (k_collide_pair): completion counters of the first step's workgroups
 	uint32_t* pair_sync; uint64_t pair_sync_words; uint32_t pair_replica_stride;
 	int fuse, pair_lag, pair_blocks_per_cu, pair_cells_together; // fuse: -1 = automatic, 0 = never, 1 = whenever a compiled instance exists; pair_lag 0 = automatic; pair_blocks_per_cu -1 = automatic
-	int pair_used, pair_used_lag, pair_used_blocks_per_cu, pair_unchecked; // what the last lbmhip_stream_collide_steps call ran (pair_used: 0 = a launch per step, 1 = k_collide_pair, 2 = k_collide_band); launches since the error word was last read
+	int pair_used, pair_used_lag, pair_used_blocks_per_cu; // what the last lbmhip_stream_collide_steps call ran (pair_used: 0 = a launch per step, 1 = k_collide_pair, 2 = k_collide_band)
 	// two time steps per launch, band by band on each XCD (k_collide_band): 16 header words (error, redo count), the completion
 	// counters, and the redo list; allocated at the first such launch
 	uint32_t* band_sync; uint64_t band_sync_words; uint64_t* band_redo; uint64_t band_redo_capacity;
@@ -286,7 +286,7 @@ int lbmhip_domain_create(const lbmhip_config* c, lbmhip_domain** out) {
 	if (e == hipSuccess) e = hipDeviceGetAttribute(&d->compute_units, hipDeviceAttributeMultiprocessorCount, c->device);
 	if (e == hipSuccess && c->Dx == 1u && c->Dy == 1u && c->Nz >= 8u) { // what k_collide_pair needs, whether or not it is ever used (264 KB at 512 planes)
 		d->pair_replica_stride = (c->Nz+63u)/64u*64u+32u; // the replicas start on different cache lines, an odd number of lines apart
-		d->pair_sync_words = (uint64_t)PAIR_REPLICAS*d->pair_replica_stride+(uint64_t)c->Nz*PAIR_SHARDS*PAIR_SHARD_STRIDE+16u;
+		d->pair_sync_words = (uint64_t)PAIR_REPLICAS*d->pair_replica_stride+(uint64_t)c->Nz*PAIR_SHARDS*PAIR_SHARD_STRIDE;
 		e = hipMalloc((void**)&d->pair_sync, d->pair_sync_words*sizeof(uint32_t));
 		if (e == hipSuccess) e = hipMemsetAsync(d->pair_sync, 0, d->pair_sync_words*sizeof(uint32_t), d->stream);
 	}
@@ -345,27 +345,18 @@ int lbmhip_get_stream(lbmhip_domain* d, void** stream) {
 	*stream = (void*)d->stream;
 	return 0;
 }
-// After the stream has been synchronised: did a wait inside a two-step launch run out?  (It cannot while workgroups are
-// dispatched in grid order; if it ever does, the lattice holds wrong values and the caller must know.)
+// After the stream has been synchronised: did a wait inside a two-step launch run out?  (It does not while workgroups are
+// dealt to the XCDs round-robin and dispatched in grid order, which HIP does not promise.)  The tasks of such waits were
+// done again by the launch behind, so this costs time only: the domain stops pairing its steps and says so once.
 static int pair_check(lbmhip_domain* d) {
-	if (d->band_unchecked && d->band_sync) { // k_collide_band: a wait that ran out cost time, not results (its tasks were redone by k_collide_seam)
-		uint32_t flag = 0u;
-		HIP_TRY(hipMemcpy(&flag, d->band_sync, sizeof(flag), hipMemcpyDeviceToHost));
-		d->band_unchecked = 0;
-		if (flag) {
-			d->band_given_up++;
-			if (d->fuse < 0 || d->fuse == 2) d->fuse = 0;
-			fprintf(stderr, "lbmhip: a two-step launch gave up waiting for its first step and finished step by step; two-step launches are now off for this domain\n");
-		}
-	}
-	if (!d->pair_unchecked || !d->pair_sync) return 0;
+	if (!d->band_unchecked || !d->band_sync) return 0;
 	uint32_t flag = 0u;
-	HIP_TRY(hipMemcpy(&flag, d->pair_sync+d->pair_sync_words-16u, sizeof(flag), hipMemcpyDeviceToHost));
-	d->pair_unchecked = 0;
-	if (flag) {
-		(void)hipMemset(d->pair_sync+d->pair_sync_words-16u, 0, sizeof(flag));
+	HIP_TRY(hipMemcpy(&flag, d->band_sync, sizeof(flag), hipMemcpyDeviceToHost));
+	d->band_unchecked = 0;
+	if (flag) { // the lattice is right (k_collide_seam ran what was given up), the time is lost
+		d->band_given_up++;
 		d->fuse = 0;
-		return fail("a two-step launch gave up waiting for its first step: the lattice is invalid (two-step launches are now off for this domain; LBMHIP_FUSE=0 avoids them)");
+		fprintf(stderr, "lbmhip: a two-step launch gave up waiting for its first step and finished step by step; two-step launches are now off for this domain\n");
 	}
 	return 0;
 }
@@ -762,12 +753,14 @@ static int pairs_steps(const lbmhip_domain* d) {
 static void note_pair_used(lbmhip_domain* d, const PairPlan& plan) {
 	d->pair_used = plan.mode; d->pair_used_lag = (int)plan.lag; d->pair_used_blocks_per_cu = plan.blocks_per_cu; d->band_used_rows = plan.mode == 2 ? (int)plan.R : 0;
 }
-static int launch_collide_band_steps(lbmhip_domain* d, const PairPlan& plan, uint64_t t, float fx, float fy, float fz, uint32_t first1, uint32_t count1, uint32_t first2, uint32_t count2) {
-	const uint32_t Nz = d->cfg.Nz, Ny = d->cfg.Ny;
-	// header (64 words: error, redo count; zeroed before every launch) + one stamp per step-t task (never cleared: the launch
-	// numbers in them rise); the redo list holds every task of step t+1 at most
-	const uint64_t header = 64u, words = header+(uint64_t)8u*plan.bands*Nz*plan.R*plan.xchunks, redo_capacity = (uint64_t)Nz*Ny*plan.xchunks;
-	if (words != d->band_sync_words || redo_capacity > d->band_redo_capacity || d->band_launches >= (1u<<28)) { // another band height lays the stamps out differently
+// What both forms of two steps per launch share: 64 header words (error, redo count; zeroed before every launch), behind them
+// k_collide_band's stamps (one per step-t task, never cleared: the launch numbers in them rise), and the redo list, which
+// holds every task of step t+1 at most.
+static const uint64_t kPairHeaderWords = 64u;
+static int pair_buffers(lbmhip_domain* d, uint64_t stamp_words, const PairPlan& plan) {
+	const uint64_t words = kPairHeaderWords+stamp_words, redo_capacity = (uint64_t)d->cfg.Nz*d->cfg.Ny*plan.xchunks;
+	const bool relayout = stamp_words > 0u && (words != d->band_sync_words || d->band_launches >= (1u<<28)); // another band height lays the stamps out differently
+	if (relayout || words > d->band_sync_words || redo_capacity > d->band_redo_capacity) {
 		HIP_TRY(hipStreamSynchronize(d->stream)); // an earlier launch may still use the old buffers
 		if (d->band_sync) HIP_TRY(hipFree(d->band_sync));
 		if (d->band_redo) HIP_TRY(hipFree(d->band_redo));
@@ -777,16 +770,21 @@ static int launch_collide_band_steps(lbmhip_domain* d, const PairPlan& plan, uin
 		HIP_TRY(fill_words(d->band_sync, 0u, words, d->stream));
 		d->band_sync_words = words; d->band_redo_capacity = redo_capacity; d->band_launches = 0u;
 	}
+	HIP_TRY(hipMemsetAsync(d->band_sync, 0, kPairHeaderWords*sizeof(uint32_t), d->stream));
+	return 0;
+}
+static int launch_collide_band_steps(lbmhip_domain* d, const PairPlan& plan, uint64_t t, float fx, float fy, float fz, uint32_t first1, uint32_t count1, uint32_t first2, uint32_t count2) {
+	const uint32_t Nz = d->cfg.Nz, Ny = d->cfg.Ny;
+	if (pair_buffers(d, (uint64_t)8u*plan.bands*Nz*plan.R*plan.xchunks, plan)) return 1;
 	NEED(count1+count2 <= 65535u && plan.bands <= 65535u, "too many planes for a two-step launch (%u)", count1+count2);
 	Args a = make_args(d, t, fx, fy, fz);
 	a.xchunks = plan.xchunks; a.z0 = 0u; a.z1 = Nz;
 	BandArgs p;
-	p.error = d->band_sync; p.redo_count = d->band_sync+1; p.stamps = d->band_sync+header; p.redo = d->band_redo;
+	p.error = d->band_sync; p.redo_count = d->band_sync+1; p.stamps = d->band_sync+kPairHeaderWords; p.redo = d->band_redo;
 	p.stamp = ++d->band_launches<<3;
 	p.block_rows = plan.block_rows; p.R = plan.R; p.bands = plan.bands; p.lag = plan.lag;
 	p.spin_limit = d->band_spin_limit >= 0 ? (uint32_t)d->band_spin_limit : 60000u; // about 0.2 s of polling (3.4 us of sleep between two polls)
 	p.first1 = first1; p.count1 = count1; p.first2 = first2; p.count2 = count2;
-	HIP_TRY(hipMemsetAsync(d->band_sync, 0, header*sizeof(uint32_t), d->stream));
 	int blocks_per_cu = plan.blocks_per_cu;
 	if (blocks_per_cu > 0) blocks_per_cu = std::max(1, blocks_per_cu*256/(int)plan.block);
 	const uint32_t lds = blocks_per_cu > 0 ? ((160u*1024u/(uint32_t)blocks_per_cu)&~255u)-256u : 0u; // the kernel has a word of LDS of its own
@@ -819,18 +817,26 @@ static int launch_collide_pair_steps(lbmhip_domain* d, const PairPlan& plan, uin
                                      uint32_t first1, uint32_t count1, uint32_t first2, uint32_t count2) {
 	DeviceGuard g(d->cfg.device);
 	if (plan.mode == 2) return launch_collide_band_steps(d, plan, t, fx, fy, fz, first1, count1, first2, count2);
+	if (pair_buffers(d, 0u, plan)) return 1;
 	Args a = make_args(d, t, fx, fy, fz);
 	a.xchunks = plan.xchunks; a.z0 = 0u; a.z1 = d->cfg.Nz;
 	PairArgs p;
 	p.first1 = first1; p.count1 = count1; p.first2 = first2; p.count2 = count2;
-	p.plane_done = d->pair_sync; p.replica_stride = d->pair_replica_stride; p.shard_done = d->pair_sync+(uint64_t)PAIR_REPLICAS*d->pair_replica_stride; p.error = d->pair_sync+d->pair_sync_words-16u;
-	p.lag = plan.lag; p.spin_limit = 500000u; // about two seconds of polling (3.4 us of sleep between two polls)
-	HIP_TRY(hipMemsetAsync(d->pair_sync, 0, (d->pair_sync_words-16u)*sizeof(uint32_t), d->stream));
+	p.plane_done = d->pair_sync; p.replica_stride = d->pair_replica_stride; p.shard_done = d->pair_sync+(uint64_t)PAIR_REPLICAS*d->pair_replica_stride;
+	p.error = d->band_sync; p.redo_count = d->band_sync+1; p.redo = d->band_redo;
+	p.lag = plan.lag; p.spin_limit = d->band_spin_limit >= 0 ? (uint32_t)d->band_spin_limit : 60000u; // about 0.2 s of polling (3.4 us of sleep between two polls)
+	HIP_TRY(hipMemsetAsync(d->pair_sync, 0, d->pair_sync_words*sizeof(uint32_t), d->stream));
 	int blocks_per_cu = plan.blocks_per_cu;
 	if (blocks_per_cu > 0) blocks_per_cu = std::max(1, blocks_per_cu*256/(int)plan.block);
-	const uint32_t lds = blocks_per_cu > 0 ? ((160u*1024u/(uint32_t)blocks_per_cu)&~255u) : 0u;
+	const uint32_t lds = blocks_per_cu > 0 ? ((160u*1024u/(uint32_t)blocks_per_cu)&~255u)-256u : 0u; // the kernel has a word of LDS of its own
 	HIP_TRY(plan.k.pair(a, p, dim3(plan.xchunks*d->cfg.Ny, count1+count2), dim3(plan.block), lds, d->stream));
-	d->pair_unchecked = 1;
+	// whatever the launch gave up: k_collide_seam without rows of its own
+	SeamArgs q;
+	q.nrows = 0u; q.first2 = first2; q.count2 = 0u; q.redo_count = p.redo_count; q.redo = p.redo;
+	Args b = make_args(d, t+1u, fx, fy, fz);
+	b.xchunks = plan.xchunks; b.z0 = 0u; b.z1 = d->cfg.Nz;
+	HIP_TRY(plan.k.seam(b, q, dim3(64u, 1u), dim3(plan.block), 0u, d->stream));
+	d->band_unchecked = 1;
 	return 0;
 }
 int lbmhip_stream_collide_steps(lbmhip_domain* d, uint64_t t, uint32_t steps, float fx, float fy, float fz) {

@@ -90,14 +90,16 @@ def test_banded_steps_equal_single_steps(gpu, kw, setup, steps, together, rows, 
         a.close(); b.close()
 
 
-def test_banded_waits_that_run_out_are_redone(gpu):
-    """A wait that gives up at once (no polls allowed, lag 2: the first step's workgroups are still running) leaves its task to the
-    launch behind; the lattice is still that of single launches, the library reports it and stops pairing."""
+@pytest.mark.parametrize("fuse", [1, 2])
+def test_waits_that_run_out_are_redone(gpu, fuse):
+    """A wait that gives up at once (no second poll allowed, the shortest lag: the first step's workgroups are still running) leaves
+    its task to the launch behind; the lattice is still that of single launches, the library reports it and stops pairing.
+    Both forms: k_collide_pair and k_collide_band."""
     kw = dict(N=(128, 64, 32), nu=0.02)
     a = cfd_amd.LBM(**kw); b = cfd_amd.LBM(**kw)
     try:
-        a.set_tuning("fuse", 2); b.set_tuning("fuse", 0)
-        a.set_tuning("band_rows", 4); a.set_tuning("band_lag", 2); a.set_tuning("band_spin_limit", 0)
+        a.set_tuning("fuse", fuse); b.set_tuning("fuse", 0)
+        a.set_tuning("pair_lag", 3); a.set_tuning("band_rows", 4); a.set_tuning("band_lag", 2); a.set_tuning("band_spin_limit", 0)
         setups.taylor_green(a); setups.taylor_green(b)
         a.run(6); b.run(6)
         assert np.array_equal(bits(a.domains[0].download_fi()), bits(b.domains[0].download_fi())), "DDFs differ"
@@ -111,9 +113,10 @@ def test_banded_waits_that_run_out_are_redone(gpu):
 
 @pytest.mark.parametrize("kw,setup", [(CHANNEL, setups.channel), (HALF_S, setups.taylor_green), (BAND_RAGGED, setups.channel)])
 def test_banded_steps_equal_the_oracle(gpu, kw, setup):
+    """Bands of two rows: three and more bands per XCD block, also on the lattice of 45 rows (blocks of 6 rows, the last one of 3)."""
     a = cfd_amd.LBM(**kw); b = H.OracleLBM(**kw)
     try:
-        a.set_tuning("fuse", 2); a.set_tuning("band_rows", 4); a.set_tuning("band_lag", 2)
+        a.set_tuning("fuse", 2); a.set_tuning("band_rows", 2); a.set_tuning("band_lag", 2)
         setup(a); setup(b)
         a.run(12); b.run(12)
         assert fused_flag(a) == 2
