@@ -12,6 +12,12 @@ PairKernels select_collide_pair(int Q, int ST, int COLL, int FEAT, int V, int P)
 	LBM_PAIR(19, ST_FP16S, COLL_SRT, 0, 2, 1)                                  // 16-bit DDFs: two cells per lane (dword accesses)
 	LBM_PAIR(19, ST_FP16S, COLL_SRT, 0, 2, 2)
 	LBM_PAIR(19, ST_FP16C, COLL_SRT, 0, 2, 1)
+	LBM_PAIR(19, ST_FP16S, COLL_TRT, F_VOLUME_FORCE|F_SUBGRID, 2, 1)           // force-driven channel, 16-bit DDFs
+	LBM_PAIR(19, ST_FP16S, COLL_TRT, F_VOLUME_FORCE|F_SUBGRID, 2, 2)
+	LBM_PAIR(27, ST_FP16C, COLL_SRT, F_FORCE_FIELD|F_VOLUME_FORCE, 2, 1)       // D3Q27 with force field (the 2048^3 configuration)
+	LBM_PAIR(27, ST_FP16C, COLL_SRT, F_FORCE_FIELD|F_VOLUME_FORCE, 2, 2)
+	LBM_PAIR(27, ST_FP16S, COLL_SRT, 0, 2, 1)
+	LBM_PAIR(27, ST_FP16C, COLL_SRT, 0, 2, 1)
 	return PairKernels{nullptr, nullptr, nullptr};
 }
 } // namespace lbm

@@ -53,7 +53,7 @@ struct lbmhip_domain {
 	float w;
 	// two time steps per launch (k_collide_pair): completion counters of the first step's workgroups
 	uint32_t* pair_sync; uint64_t pair_sync_words; uint32_t pair_replica_stride;
-	int fuse, pair_lag, pair_blocks_per_cu, pair_cells_together; // fuse: -1 = automatic, 0 = never, 1 = whenever a compiled instance exists; pair_lag 0 = automatic; pair_blocks_per_cu -1 = automatic
+	int fuse, pair_lag, pair_blocks_per_cu, pair_cells_together, pair_block; // fuse: -1 = automatic, 0 = never, 1 = whenever a compiled instance exists; pair_lag 0 = automatic; pair_blocks_per_cu -1 = automatic
 	int pair_used, pair_used_lag, pair_used_blocks_per_cu; // what the last lbmhip_stream_collide_steps call ran (pair_used: 0 = a launch per step, 1 = k_collide_pair, 2 = k_collide_band)
 	// two time steps per launch, band by band on each XCD (k_collide_band): 16 header words (error, redo count), the completion
 	// counters, and the redo list; allocated at the first such launch
@@ -459,6 +459,7 @@ int lbmhip_set_tuning(lbmhip_domain* d, const char* key, int value) {
 	if (!strcmp(key, "band_spin_limit")) { NEED(value >= -1, "band_spin_limit must be -1 (default) or a number of polls"); d->band_spin_limit = value; return 0; }
 	if (!strcmp(key, "pair_lag")) { NEED(value == 0 || (value >= 3 && value <= 64), "pair_lag must be 0 (auto) or 3..64"); d->pair_lag = value; return 0; }
 	if (!strcmp(key, "pair_cells_together")) { NEED(value == 1 || value == 2, "pair_cells_together must be 1 or 2"); d->pair_cells_together = value; return 0; }
+	if (!strcmp(key, "pair_block")) { NEED(value == 0 || (value >= 64 && value <= 256 && value%64 == 0), "pair_block must be 0 (auto), 64, 128, 192 or 256"); d->pair_block = value; return 0; }
 	if (!strcmp(key, "pair_blocks_per_cu")) { NEED(value >= -1 && value <= 32, "pair_blocks_per_cu must be -1 (auto), 0 (no limit) or 1..32"); d->pair_blocks_per_cu = value; return 0; }
 	return fail("unknown tuning key '%s'", key);
 }
@@ -479,6 +480,7 @@ int lbmhip_get_tuning(lbmhip_domain* d, const char* key, int* value) {
 	if (!strcmp(key, "band_given_up")) { *value = d->band_given_up; return 0; } // two-step launches whose waits ran out (checked when the stream is synchronised)
 	if (!strcmp(key, "pair_lag")) { *value = d->pair_used ? d->pair_used_lag : d->pair_lag; return 0; }
 	if (!strcmp(key, "pair_cells_together")) { *value = d->pair_cells_together; return 0; }
+	if (!strcmp(key, "pair_block")) { *value = d->pair_block; return 0; }
 	if (!strcmp(key, "pairs_steps")) { *value = pairs_steps(d); return 0; } // would two steps of this domain share a launch (whole lattice, or the inner planes of a z-slab)?
 	if (!strcmp(key, "pair_blocks_per_cu")) { *value = d->pair_used ? d->pair_used_blocks_per_cu : d->pair_blocks_per_cu; return 0; }
 	return fail("unknown tuning key '%s'", key);
@@ -716,6 +718,10 @@ static bool pair_plan(const lbmhip_domain* d, PairPlan* plan) {
 	if (!plan->k.pair) return false;
 	const uint32_t lanes_per_row = d->cfg.Nx/V;
 	plan->block = std::min(256u, (lanes_per_row+63u)/64u*64u);
+	// rows whose last 256-lane chunk would be less than half full: 128-lane workgroups (1600^3 FP16S, 800 lanes per row: 85.8 % of 8 TB/s
+	// against 71.6 %); where the rows fill whole 256-lane chunks those are 1-5 % faster
+	if (plan->block == 256u && (lanes_per_row+255u)/256u*256u-lanes_per_row >= 128u+((lanes_per_row+127u)/128u*128u-lanes_per_row)) plan->block = 128u;
+	if (d->pair_block) plan->block = std::min(plan->block, (uint32_t)d->pair_block);
 	plan->xchunks = (lanes_per_row+plan->block-1u)/plan->block;
 	const uint64_t per_plane = (uint64_t)plan->xchunks*d->cfg.Ny;
 	if (per_plane*plan->block >= 0xFFFFFFFFull || 2u*d->cfg.Nz > 65535u) return false;
@@ -727,8 +733,11 @@ static bool pair_plan(const lbmhip_domain* d, PairPlan* plan) {
 	if (d->fuse < 0 && !(band_possible && plain && (uint64_t)d->cfg.Nx*d->cfg.Ny >= 256ull*256ull)) return false; // automatic mode: where it was measured to pay
 	plan->mode = (d->fuse != 1 && band_possible) ? 2 : 1;
 	if (plan->mode == 2) {
-		// 32 tasks per plane of a band measured best at 512^3 (FP32: 16 rows of two chunks, 16-bit DDFs: 32 rows of one), flat from 16 to 64
-		plan->R = std::max(2u, std::min(d->band_rows > 0 ? (uint32_t)d->band_rows : std::max(2u, 32u/plan->xchunks), plan->block_rows));
+		// tasks per plane of a band, measured with Taylor-Green lattices (tools/fused_sweep.py): 64 for 16-bit DDFs (512^3: 64 rows of one chunk
+		// 80.2 % of 8 TB/s, 32 rows 76.8 %; 1024^3: 32 rows of two chunks 76.5 %, 16 rows 74.6 %) and for FP32 rows of four chunks and more
+		// (1024^3: 16 rows 85.2 %, 8 rows 80.0 %), 32 for shorter FP32 rows (512^3: 8 to 64 rows 89.7 to 88.2 %)
+		const uint32_t per_plane_wanted = (half || plan->xchunks > 2u) ? 64u : 32u;
+		plan->R = std::max(2u, std::min(d->band_rows > 0 ? (uint32_t)d->band_rows : std::max(2u, per_plane_wanted/plan->xchunks), plan->block_rows));
 		plan->bands = (plan->block_rows+plan->R-1u)/plan->R;
 		plan->blocks_per_cu = d->band_blocks_per_cu >= 0 ? d->band_blocks_per_cu : 0; // every residency cap lost at 512^3 (FP32: 88.5 % of 8 TB/s without, 86.5 % with 6, 82 % with 5 workgroups per CU)
 		// the workgroups of an XCD that are resident together cover `resident` tasks of its queue; step t+1 follows far enough behind

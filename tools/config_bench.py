@@ -1,14 +1,17 @@
 """Diagnostic: single-GPU stream_collide rate of the five benchmark configurations (GPU needed).  The lattices start at
 rest (the rate does not depend on the field data); solids are an extruded pillar mask uploaded plane by plane, so no
 host copy of the big lattices is ever made.
-usage: python tools/config_bench.py [--sweep] [--geometry=V,P,blocks_per_cu,block] [--steps=n] [names...]
-(--sweep also tries every launch geometry; --geometry fixes it and skips the library's search, for profiler passes that must see one kernel)"""
+usage: python tools/config_bench.py [--sweep] [--geometry=V,P,blocks_per_cu,block] [--steps=n] [--fuse=-1|1|2] [--band=rows,lag,blocks_per_cu[,lanes per workgroup]] [--together=1|2] [--moving] [names...]
+(--sweep also tries every launch geometry; --geometry fixes it and skips the library's search, for profiler passes that must see one kernel;
+--fuse hands the timed steps to lbmhip_stream_collide_steps in one call with that "fuse" setting: two steps per launch where the library has an
+instance, --band fixes k_collide_band's geometry; --moving starts from a vortex field instead of a lattice at rest)"""
 import ctypes as C
 import sys
 
 import numpy as np
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import cfd_amd
 from cfd_amd import lbm as L
 from cfd_amd import setups
@@ -65,6 +68,17 @@ def run(name, c):
             if c.get("walls"):  # moving lid
                 lid = np.full(Nx * Ny, 0.1, dtype=np.float32)
                 dom.upload(L.FIELD_U, lid, offset=(dom.N + (Nz - 1) * Nx * Ny) * 4)
+        if MOVING:  # a velocity field that varies in all three directions, uploaded plane by plane (a lattice at rest holds zeros only, and
+            # the two-step launches then run several per cent faster than with real data)
+            xs = (np.arange(Nx, dtype=np.float32) + 0.5) * np.float32(2.0 * np.pi / Nx)
+            ys = (np.arange(Ny, dtype=np.float32) + 0.5) * np.float32(2.0 * np.pi / Ny)
+            cs, sn = np.cos(xs)[None, :], np.sin(xs)[None, :]
+            cy, sy = np.cos(ys)[:, None], np.sin(ys)[:, None]
+            base = [np.ascontiguousarray(0.05 * cs * sy, dtype=np.float32), np.ascontiguousarray(-0.05 * sn * cy, dtype=np.float32), np.ascontiguousarray(0.02 * sn * sy, dtype=np.float32)]
+            for z in range(Nz):
+                cz = 2.0 * np.pi * (z + 0.5) / Nz
+                for comp, scale in enumerate((np.sin(cz), np.sin(cz), np.cos(cz))):
+                    dom.upload(L.FIELD_U, base[comp] * np.float32(scale), offset=(comp * dom.N + z * Nx * Ny) * 4)
         L.check(lib.lbmhip_initialize(dom.h))
         f = c.get("f", (0.0, 0.0, 0.0))
         step = lambda t: L.check(lib.lbmhip_stream_collide(dom.h, C.c_uint64(t), C.c_float(f[0]), C.c_float(f[1]), C.c_float(f[2])))
@@ -84,6 +98,25 @@ def run(name, c):
             return per, "%-26s %5dx%4dx%4d  %-22s %.3f ms/step  %7.0f MLUPs/s  %4d B/cell  %5.0f GB/s (%.1f%% of 8 TB/s)" % (
                 name, Nx, Ny, Nz, label, per, dom.N / per / 1e3, B, B * dom.N / per / 1e6, B * dom.N / per / 1e6 / 80)
 
+        if FUSE is not None:
+            L.check(lib.lbmhip_set_tuning(dom.h, b"fuse", FUSE))
+            L.check(lib.lbmhip_set_tuning(dom.h, b"pair_cells_together", TOGETHER))
+            for key, val in zip(("band_rows", "band_lag", "band_blocks_per_cu", "pair_block"), BAND or ()):
+                L.check(lib.lbmhip_set_tuning(dom.h, key.encode(), val))
+
+            def measure(label, warm=6):  # noqa: F811 - the steps of a measurement in one call
+                call = lambda n: L.check(lib.lbmhip_stream_collide_steps(dom.h, C.c_uint64(t[0]), n, C.c_float(f[0]), C.c_float(f[1]), C.c_float(f[2])))
+                call(warm); t[0] += warm
+                n = STEPS or max(10, min(400, int(4e9 / dom.N)))
+                n += n % 2
+                ms = C.c_float()
+                L.check(lib.lbmhip_timer_start(dom.h))
+                call(n); t[0] += n
+                L.check(lib.lbmhip_timer_stop(dom.h, C.byref(ms)))
+                per = ms.value / n
+                v = C.c_int(); L.check(lib.lbmhip_get_tuning(dom.h, b"fused", C.byref(v)))
+                return per, "%-26s %5dx%4dx%4d  %-22s %.3f ms/step  %7.0f MLUPs/s  %4d B/cell  %5.0f GB/s (%.1f%% of 8 TB/s)" % (
+                    name, Nx, Ny, Nz, "fuse %d -> form %d" % (FUSE, v.value), per, dom.N / per / 1e3, B, B * dom.N / per / 1e6, B * dom.N / per / 1e6 / 80)
         if GEOMETRY:
             for key, val in zip(("cells_per_thread", "cells_together", "blocks_per_cu", "block"), GEOMETRY):
                 L.check(lib.lbmhip_set_tuning(dom.h, key.encode(), val))
@@ -119,6 +152,10 @@ SWEEP = "--sweep" in sys.argv or "--sweep-blocks" in sys.argv
 BLOCKS = (0, 192, 128, 64) if "--sweep-blocks" in sys.argv else (0,)
 GEOMETRY = next((tuple(int(v) for v in a.split("=")[1].split(",")) for a in sys.argv[1:] if a.startswith("--geometry=")), None)
 STEPS = next((int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--steps=")), 0)
+FUSE = next((int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--fuse=")), None)
+MOVING = "--moving" in sys.argv
+TOGETHER = next((int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--together=")), 1)
+BAND = next((tuple(int(v) for v in a.split("=")[1].split(",")) for a in sys.argv[1:] if a.startswith("--band=")), None)
 names = [a for a in sys.argv[1:] if not a.startswith("--")]
 for name in (names or list(CONFIGS)):
     run(name, CONFIGS[name])

@@ -1,7 +1,7 @@
 """Diagnostic: step rate of lbmhip_stream_collide_steps (two time steps per launch) over its lag and residency cap,
 against one launch per step.  (GPU needed)
 
-usage: [SWEEP_CAPS=0,6,4,3] [SWEEP_LAGS=3,4,5,6,7,8] [SWEEP_BAND_ROWS=8,16] [SWEEP_BAND_LAGS=0,3,4] [SWEEP_BAND_CAPS=3,4,0]
+usage: [SWEEP_CAPS=0,6,4,3] [SWEEP_LAGS=3,4,5,6,7,8] [SWEEP_BAND_ROWS=8,16] [SWEEP_BAND_LAGS=0,3,4] [SWEEP_BAND_CAPS=3,4,0] [SWEEP_BAND_BLOCK=128]
        python tools/fused_sweep.py [n] [config: tgv|channel] [storage] [cells collided together in the paired kernel: 1|2]
 SWEEP_CAPS / SWEEP_LAGS empty: skip the sweep of k_collide_pair; SWEEP_BAND_ROWS (default empty) sweeps k_collide_band (lag 0 = automatic).
 """
@@ -62,6 +62,7 @@ for cap in caps:
         lbm.set_tuning("pair_lag", lag); lbm.set_tuning("pair_blocks_per_cu", cap)
         print("%s %s %d^3 two steps per launch, lag %d, blocks/CU<=%d: %.3f ms/step %7.0f MLUPs/s %.1f %% of 8 TB/s" % ((config, storage, n, lag, cap) + rate(40)), flush=True)
 lbm.set_tuning("fuse", 2)
+lbm.set_tuning("pair_block", int(os.environ.get("SWEEP_BAND_BLOCK", "0")))  # lanes per workgroup (0 = automatic)
 for rows in ints("SWEEP_BAND_ROWS", ""):
     for cap in ints("SWEEP_BAND_CAPS", "3,4,0"):
         for lag in ints("SWEEP_BAND_LAGS", "0,3,4,6"):
