@@ -1,7 +1,5 @@
 set -x
-timeout -k 10 280 python -u tools/config_bench.py --moving --fuse=-1 tgv512_fp32 || exit 1
-timeout -k 10 280 python -u tools/config_bench.py --moving --fuse=-1 fp32_1024 || exit 1
-timeout -k 10 500 python -u tools/config_bench.py --moving --steps=20 capacity1600_fp16s || exit 1
-timeout -k 10 500 python -u tools/config_bench.py --moving --steps=20 --fuse=-1 capacity1600_fp16s || exit 1
-timeout -k 10 500 python -u tools/config_bench.py --moving --steps=20 --fuse=-1 --band=16,0,0 capacity1600_fp16s || exit 1
-timeout -k 10 500 python -u tools/config_bench.py --moving --steps=20 --fuse=-1 --band=32,0,0 capacity1600_fp16s || exit 1
+for name in channel512_trt_sgs_fp16s channel512_trt_sgs gui512_fp16s q27_fp16c_force_slab tgv512_fp32_sgs; do
+  timeout -k 10 280 python -u tools/config_bench.py $name || exit 1
+  timeout -k 10 280 python -u tools/config_bench.py --fast-div $name || exit 1
+done
