@@ -1139,9 +1139,10 @@ int lbmhip_voxelize_mesh(lbmhip_domain* d, uint32_t direction, uint64_t t, uint8
 	return voxelize_with_buffer(d, static_cast<float*>(d->mesh), direction, t, flag, p0, p1, p2, triangles, bounding_box, rotation_center, linear_velocity, rotational_velocity);
 }
 
-// The same call for callers that must not allocate device memory (code under graph capture, serving loops, harnesses that
-// forbid hipMalloc): the triangles are staged in a fixed array in the library's device image.  Every GPU holds its own copy
-// of the array at its own address; host code may only use that address, looked up once per device, never the array's name.
+// The same call for callers that must not allocate device memory (serving loops, harnesses that forbid hipMalloc): the
+// triangles are staged in a fixed array in the library's device image.  Every GPU holds its own copy of the array at its own
+// address; host code may only use that address, looked up once per device, never the array's name.  The call copies from the
+// caller's host arrays and waits for its stream, like lbmhip_voxelize_mesh, so it is not for a stream under graph capture.
 static __device__ __align__(256) float scratch[kMeshFloatsPerTriangle*LBMHIP_STATIC_MESH_TRIANGLES];
 static int scratch_address(int device, float** out) { // the device must be current
 	static std::mutex lock;
@@ -1165,6 +1166,8 @@ int lbmhip_voxelize_mesh_static(lbmhip_domain* d, uint32_t direction, uint64_t t
 	NEED(g.ok, "cannot select device %d", d->cfg.device);
 	float* dev = nullptr;
 	if (scratch_address(d->cfg.device, &dev)) return 1;
+	static std::mutex in_use[64]; // one array per GPU: calls of several host threads or domains on one GPU take turns
+	std::lock_guard<std::mutex> hold(in_use[d->cfg.device]);
 	return voxelize_with_buffer(d, dev, direction, t, flag, p0, p1, p2, triangles, bounding_box, rotation_center, linear_velocity, rotational_velocity);
 }
 int lbmhip_unvoxelize_mesh(lbmhip_domain* d, uint8_t flag, const float* bounding_box) {

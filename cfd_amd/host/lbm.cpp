@@ -88,32 +88,40 @@ string default_filename(const string& name, const string& extension, const ulong
 
 static void check(const int status) { if (status) print_error(lbmhip_last_error()); }
 
+// Binary STL (utilities.hpp:4530-4572 reads the same format): 80 header bytes, the triangle count, then 50 bytes per triangle -
+// normal, three corners of three floats each, two attribute bytes.  Corners are rotated as they are read; the mesh is then
+// scaled (size 0: to fit the box; > 0: longest side to that length; < 0: by -size) about the middle of its bounding box
+// (reposition) or about the origin, and moved to `center`.  The arithmetic per corner, center+scale*(shift+p), is the
+// reference's: the voxelizer's flags depend on every bit of it.
+namespace {
+vector<char> whole_file(const string& filename) {
+	std::ifstream in(filename, std::ios::in|std::ios::binary);
+	if (in.fail()) print_error("File \""+filename+"\" does not exist!");
+	return vector<char>((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+}
+float3 stl_corner(const vector<char>& bytes, const uint triangle, const int corner) {
+	float c[3];
+	std::memcpy(c, bytes.data()+84ull+50ull*(ulong)triangle+12ull*(ulong)(corner+1), sizeof(c));
+	return float3(c[0], c[1], c[2]);
+}
+} // namespace
 Mesh* read_stl_raw(const string& path, const bool reposition, const float3& box_size, const float3& center, const float3x3& rotation, const float size) {
 	const string filename = create_file_extension(path, ".stl");
-	std::ifstream file(filename, std::ios::in|std::ios::binary);
-	if (file.fail()) print_error("File \""+filename+"\" does not exist!");
-	vector<char> data((std::istreambuf_iterator<char>(file)), std::istreambuf_iterator<char>());
-	if (data.size() < 84u) print_error("File \""+filename+"\" is corrupt!");
-	uint triangle_number = 0u;
-	std::memcpy(&triangle_number, data.data()+80, 4);
-	if (triangle_number == 0u || data.size() != 84ull+50ull*(ulong)triangle_number) print_error("File \""+filename+"\" is corrupt or unsupported! Only binary .stl files are supported.");
-	print_info("Loading \""+filename+"\" with "+to_string(triangle_number)+" triangles.");
-	Mesh* mesh = new Mesh(triangle_number, center);
-	for (uint i = 0u; i < triangle_number; i++) { // 50 bytes per triangle: normal, three corners, attribute
-		float v[12];
-		std::memcpy(v, data.data()+84ull+50ull*(ulong)i, 48);
-		mesh->p0[i] = rotation*float3(v[3], v[4], v[5]);
-		mesh->p1[i] = rotation*float3(v[6], v[7], v[8]);
-		mesh->p2[i] = rotation*float3(v[9], v[10], v[11]);
-	}
+	const vector<char> bytes = whole_file(filename);
+	if (bytes.size() < 84u) print_error("File \""+filename+"\" is corrupt!");
+	uint count = 0u;
+	std::memcpy(&count, bytes.data()+80, sizeof(count));
+	if (count == 0u || bytes.size() != 84ull+50ull*(ulong)count) print_error("File \""+filename+"\" is corrupt or unsupported! Only binary .stl files are supported.");
+	print_info("Loading \""+filename+"\" with "+to_string(count)+" triangles.");
+	Mesh* const mesh = new Mesh(count, center);
+	float3* const corners[3] = {mesh->p0.data(), mesh->p1.data(), mesh->p2.data()};
+	for (int k = 0; k < 3; k++) for (uint t = 0u; t < count; t++) corners[k][t] = rotation*stl_corner(bytes, t, k);
 	mesh->find_bounds();
-	const float scale = size == 0.0f ? mesh->get_scale_for_box_fit(box_size) : size > 0.0f ? size/mesh->get_max_size() : -size;
-	const float3 offset = reposition ? -0.5f*(mesh->pmin+mesh->pmax) : float3(0.0f);
-	for (uint i = 0u; i < triangle_number; i++) {
-		mesh->p0[i] = center+scale*(offset+mesh->p0[i]);
-		mesh->p1[i] = center+scale*(offset+mesh->p1[i]);
-		mesh->p2[i] = center+scale*(offset+mesh->p2[i]);
-	}
+	float scale = -size;                                                   // relative to the file's own size
+	if (size == 0.0f) scale = mesh->get_scale_for_box_fit(box_size);       // as large as the box allows
+	else if (size > 0.0f) scale = size/mesh->get_max_size();               // longest side of the bounding box
+	const float3 shift = reposition ? -0.5f*(mesh->pmin+mesh->pmax) : float3(0.0f);
+	for (int k = 0; k < 3; k++) for (uint t = 0u; t < count; t++) corners[k][t] = center+scale*(shift+corners[k][t]);
 	mesh->find_bounds();
 	return mesh;
 }
@@ -384,7 +392,9 @@ void LBM::do_two_time_steps() {
 	for (LBM_Domain* d : lbm_domain) d->increment_time_step();
 }
 
+std::atomic<unsigned long> lbm_runs_after_stop(0ul); // LBM::run calls made although `running` is false (main.cpp's watchdog reads it)
 void LBM::run(const ulong steps, const ulong total_steps) { // lbm.cpp:1461-1489
+	if (!running && steps > 0ull) lbm_runs_after_stop++;
 	info.append(steps, total_steps, get_t());
 	if (!initialized) initialize();
 	Clock clock;

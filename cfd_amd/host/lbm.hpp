@@ -3,6 +3,7 @@
 // flags/rho/u/F containers with operator[] and .x/.y/.z, run(), update_fields(), read_from_device(), VTK export,
 // coordinates()/index()/position()/center()/size().  All lattice arithmetic happens in the HIP kernels.
 #pragma once
+#include <atomic>
 #include <fstream>
 #include "defines.hpp"
 #include "utilities.hpp"
@@ -62,6 +63,8 @@ public:
 	void read_from_device() { if (count() && lbmhip_download(domain, field, host, 0ull, count()*sizeof(T))) print_error(lbmhip_last_error()); }
 	void write_to_device() { if (count() && lbmhip_upload(domain, field, host, 0ull, count()*sizeof(T))) print_error(lbmhip_last_error()); }
 };
+
+extern std::atomic<unsigned long> lbm_runs_after_stop; // LBM::run calls made although `running` is false
 
 class LBM_Domain { // one lattice block on one GPU (lbm.hpp:20-204)
 	uint Nx = 1u, Ny = 1u, Nz = 1u, Dx = 1u, Dy = 1u, Dz = 1u;

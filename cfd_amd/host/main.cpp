@@ -6,10 +6,11 @@
 // A setup sees them through the same globals as in the reference: running, key_P, key_9.
 //
 // SIGINT / SIGTERM never leave the process unkillable.  The first one clears `running`, so that LBM::run returns at its
-// next batch and a setup that tests `running` can export and leave; the handler is installed with SA_RESETHAND, so a second
-// signal has the default effect (the reference does not intercept these signals at all, main.cpp:362-381); and a watchdog
-// ends the process with status 128+signal if it is still alive LBM_STOP_GRACE_MS (default 5000) after the first one -
-// a setup loop such as `while(lbm.get_t()<T) lbm.run(n);` that never looks at `running` would otherwise spin forever.
+// next batch and a setup that tests `running` can export and leave - however long its exports take; the handler is installed
+// with SA_RESETHAND, so a second signal has the default effect (the reference does not intercept these signals at all,
+// main.cpp:362-381).  A setup loop such as `while(lbm.get_t()<T) lbm.run(n);` that never looks at `running` would spin forever
+// on calls that return at once: a watchdog counts those calls (lbm_runs_after_stop, lbm.cpp) and, once the setup has made a
+// hundred of them, ends the process with status 128+signal LBM_STOP_GRACE_MS (default 5000) later.
 #include <atomic>
 #include <chrono>
 #include <csignal>
@@ -47,6 +48,7 @@ int main(int argc, char* argv[]) {
 	std::thread watchdog([grace_ms]() { // ends with the process
 		while (!stop_signal) std::this_thread::sleep_for(std::chrono::milliseconds(50));
 		const int s = stop_signal;
+		while (lbm_runs_after_stop.load() < 100ul) std::this_thread::sleep_for(std::chrono::milliseconds(50)); // a setup that has stopped stepping is left to finish its exports
 		std::this_thread::sleep_for(std::chrono::milliseconds(grace_ms));
 		_exit(128+s);
 	});

@@ -1,12 +1,31 @@
 // units.hpp - SI <-> lattice unit conversion.  The method names, argument orders and meanings MIRROR the reference's Units
 // class (FluidX3D-master/src/units.hpp:5-161) on purpose: setups written for the reference call them and must compile
-// unchanged.  Only what the reference's lattice-Boltzmann setups without free surface, temperature or particles call is
-// provided (base units, SI <-> lattice conversions, Reynolds number, viscosity/velocity/force relations, Poiseuille and
-// Stokes flow); the other dimensionless numbers and *_from_* helpers of the reference's class are left out.
+// unchanged.  The whole set is provided: base units, SI <-> lattice conversions, the dimensionless numbers and the
+// *_from_* relations (each once, in `Relations`, for both unit systems: a dimensionless number or a relation between
+// quantities reads the same in lattice and in SI units), Poiseuille and Stokes flow.
 // Outputs are converted by their dimension: one lattice unit of a quantity with dimension m^L kg^M s^T K^H is
 // dim(L, M, T, H) SI units and "si_q(v)" multiplies by it.
 #pragma once
 #include "utilities.hpp"
+
+// Definitions shared by the lattice-unit members (Re, We, u_from_Re, ...) and the SI members (si_Re, si_We, si_u_from_si_Re, ...)
+// of Units.  x length, u velocity, nu / mu kinematic / dynamic viscosity, rho density, sigma surface tension, g acceleration,
+// f force per volume.
+struct Relations {
+	static float reynolds(const float x, const float u, const float nu) { return x*u/nu; }
+	static float reynolds(const float x, const float u, const float mu, const float rho) { return x*u*rho/mu; }
+	static float weber(const float x, const float u, const float rho, const float sigma) { return x*sq(u)*rho/sigma; }                  // inertia against surface tension
+	static float froude(const float x, const float u, const float g) { return u/sqrt(x*g); }                                              // inertia against gravity
+	static float capillary(const float u, const float mu, const float sigma) { return u*mu/sigma; }                                        // viscous force against surface tension
+	static float bond(const float x, const float rho, const float g, const float sigma) { return sq(x)*rho*g/sigma; }                     // gravity against surface tension
+	static float morton(const float rho, const float delta_rho, const float g, const float sigma, const float mu) { return g*delta_rho*sq(sq(mu))/(cb(sigma)*sq(rho)); }
+	static float galilei(const float x, const float nu, const float g) { return cb(x)*g/sq(nu); }                                          // gravity against viscous force
+	static float velocity_for_reynolds(const float Re, const float x, const float nu) { return Re*nu/x; }
+	static float velocity_for_weber(const float We, const float x, const float sigma, const float rho) { return sqrt(We*sigma/(x*rho)); }
+	static float velocity_for_froude(const float Fr, const float x, const float g) { return Fr*sqrt(x*g); }
+	static float poiseuille_centre_velocity_2D(const float Q, const float R) { return 0.75f*Q/R; }          // flow rate Q per unit depth between plates 2R apart
+	static float poiseuille_centre_velocity_3D(const float Q, const float R) { return 2.0f/pif*Q/sq(R); }  // flow rate Q through a pipe of radius R
+};
 
 class Units {
 	float base[4] = {1.0f, 1.0f, 1.0f, 1.0f}; // one lattice unit of length, mass, time, temperature in m, kg, s, K
@@ -75,15 +94,54 @@ public:
 	float si_alpha(const float alpha) const { return alpha*dim(2, 0, -1); }
 	float si_beta(const float beta) const { return beta*dim(0, 0, 0, -1); }
 
-	// ---- Reynolds number (the same in both unit systems)
+	// ---- dimensionless numbers, from lattice quantities and from SI quantities (units.hpp:79-90, 137-147)
+	float Re(const float si_Re) const { return si_Re; }
+	float Re(const float x, const float u, const float nu) const { return Relations::reynolds(x, u, nu); }
+	float Re(const float x, const float u, const float mu, const float rho) const { return Relations::reynolds(x, u, mu, rho); }
+	float We(const float x, const float u, const float rho, const float sigma) const { return Relations::weber(x, u, rho, sigma); }
+	float Fr(const float x, const float u, const float g) const { return Relations::froude(x, u, g); }
+	float Ca(const float u, const float mu, const float sigma) const { return Relations::capillary(u, mu, sigma); }
+	float Ca(const float u, const float rho, const float nu, const float sigma) const { return Relations::capillary(u, rho*nu, sigma); }
+	float Bo(const float x, const float rho, const float g, const float sigma) const { return Relations::bond(x, rho, g, sigma); }
+	float Mo(const float rho, const float delta_rho, const float g, const float sigma, const float mu) const { return Relations::morton(rho, delta_rho, g, sigma, mu); }
+	float Ga(const float x, const float nu, const float g) const { return Relations::galilei(x, nu, g); }
+	float Ga(const float x, const float rho, const float nu, const float f) const { return cb(x)*f/(sq(nu)*rho); } // with g = f/rho
+	float Ma(const float u) const { return u/0.57735027f; } // against the lattice speed of sound 1/sqrt(3)
 	float si_Re(const float Re) const { return Re; }
-	float si_Re(const float si_x, const float si_u, const float si_nu) const { return si_x*si_u/si_nu; }
-	float si_Re(const float si_x, const float si_u, const float si_mu, const float si_rho) const { return si_x*si_u*si_rho/si_mu; }
+	float si_Re(const float si_x, const float si_u, const float si_nu) const { return Relations::reynolds(si_x, si_u, si_nu); }
+	float si_Re(const float si_x, const float si_u, const float si_mu, const float si_rho) const { return Relations::reynolds(si_x, si_u, si_mu, si_rho); }
+	float si_We(const float si_x, const float si_u, const float si_rho, const float si_sigma) const { return Relations::weber(si_x, si_u, si_rho, si_sigma); }
+	float si_Fr(const float si_x, const float si_u, const float si_g) const { return Relations::froude(si_x, si_u, si_g); }
+	float si_Ca(const float si_u, const float si_mu, const float si_sigma) const { return Relations::capillary(si_u, si_mu, si_sigma); }
+	float si_Ca(const float si_u, const float si_rho, const float si_nu, const float si_sigma) const { return Relations::capillary(si_u, si_rho*si_nu, si_sigma); }
+	float si_Bo(const float si_x, const float si_rho, const float si_g, const float si_sigma) const { return Relations::bond(si_x, si_rho, si_g, si_sigma); }
+	float si_Mo(const float si_rho, const float si_delta_rho, const float si_g, const float si_sigma, const float si_mu) const { return Relations::morton(si_rho, si_delta_rho, si_g, si_sigma, si_mu); }
+	float si_Ga(const float si_x, const float si_nu, const float si_g) const { return Relations::galilei(si_x, si_nu, si_g); }
+	float si_Ga(const float si_x, const float si_rho, const float si_nu, const float si_f) const { return cb(si_x)*si_f/(sq(si_nu)*si_rho); }
 
-	// ---- relations in lattice units: equation of state p = (rho-1)/3, viscosity from relaxation time, parameters from numbers
+	// ---- relations in lattice units (units.hpp:91-112): equation of state p = (rho-1)/3 (speed of sound 1/sqrt(3), rho0 = 1),
+	// viscosity from the relaxation time, parameters from dimensionless numbers
+	float p_from_rho(const float rho) const { return (rho-1.0f)/3.0f; }
+	float rho_from_p(const float p) const { return 1.0f+3.0f*p; }
+	float rho_laplace(const float sigma, const float R) const { return 6.0f*sigma/R; }                        // density offset of the Laplace pressure 2 sigma / R inside a sphere
+	float rho_hydrostatic(const float f, const float z, const float h) const { return 3.0f*f*(h-z)+1.0f; }   // density at height z under a column of height h, force per volume f
+	float nu_from_mu(const float mu, const float rho) const { return mu/rho; }
 	float nu_from_tau(const float tau) const { return (tau-0.5f)/3.0f; }
 	float nu_from_Re(const float Re, const float x, const float u) const { return x*u/Re; }
-	float u_from_Re(const float Re, const float x, const float nu) const { return Re*nu/x; }
+	float f_from_F(const float F, const float V) const { return F/V; }
+	float f_from_g(const float g, const float rho) const { return rho*g; }
+	float g_from_f(const float f, const float rho) const { return f/rho; }
+	float u_from_Re(const float Re, const float x, const float nu) const { return Relations::velocity_for_reynolds(Re, x, nu); }
+	float u_from_Re(const float Re, const float x, const float mu, const float rho) const { return Re*mu/(x*rho); }
+	float u_from_Ma(const float Ma) const { return 0.57735027f*Ma; }
+	float u_from_We(const float We, const float x, const float sigma, const float rho) const { return Relations::velocity_for_weber(We, x, sigma, rho); }
+	float u_from_Fr(const float Fr, const float x, const float g) const { return Relations::velocity_for_froude(Fr, x, g); }
+	float u_from_Ca(const float Ca, const float sigma, const float nu, const float rho) const { return Ca*sigma/(rho*nu); }
+	float u_from_Ca(const float Ca, const float sigma, const float mu) const { return Ca*sigma/mu; }
+	float u_from_f_Poiseuille_2D(const float f, const float rho, const float nu, const float R) const { return f*sq(R)/(2.0f*rho*nu); }
+	float u_from_f_Poiseuille_3D(const float f, const float rho, const float nu, const float R) const { return f*sq(R)/(4.0f*rho*nu); }
+	float u_from_f_Poiseuille_2D(const float Q, const float R) const { return Relations::poiseuille_centre_velocity_2D(Q, R); }
+	float u_from_f_Poiseuille_3D(const float Q, const float R) const { return Relations::poiseuille_centre_velocity_3D(Q, R); }
 	// Poiseuille flow: centre velocity u = f R^2 / (2 rho nu) between plates, f R^2 / (4 rho nu) in a pipe
 	float f_from_u_Poiseuille_2D(const float u, const float rho, const float nu, const float R) const { return 2.0f*u*rho*nu/sq(R); }
 	float f_from_u_Poiseuille_3D(const float u, const float rho, const float nu, const float R) const { return 4.0f*u*rho*nu/sq(R); }
@@ -95,8 +153,9 @@ public:
 		const double pi3 = 3.14159265358979323846*3.14159265358979323846*3.14159265358979323846;
 		return (float)(pi3*(double)rho*(double)nu*(double)u/(4.0*(double)h*(double)h)/series);
 	}
-	// Stokes flow past a sphere of radius R: drag 6 pi rho nu R u
+	// Stokes flow past a sphere of radius R: drag 6 pi rho nu R u, also spread over a volume V
 	float F_Stokes(const float rho, const float u, const float nu, const float R) const { return 6.0f*pif*rho*nu*R*u; }
+	float f_Stokes(const float rho, const float u, const float nu, const float R, const float V) const { return F_Stokes(rho, u, nu, R)/V; }
 	// creeping flow of far-field velocity u0 past a fixed sphere of radius R at the origin (FluidX3D-master/src/units.hpp:125-132):
 	// u = u0 - (3R/4)(u0/r + x (u0.x)/r^3) - (R^3/4)(u0/r^3 - 3 x (u0.x)/r^5), p = -(3/2) rho nu R (u0.x)/r^3, rho = rho0 + 3p
 	float3 u_Stokes(const float3& x, const float3& u0, const float R) const {
@@ -110,7 +169,18 @@ public:
 		return r > R ? rho-4.5f*rho*nu*R*dot(u0, x)/(r*r*r) : rho;
 	}
 
-	// ---- the same relations for SI inputs
+	// ---- the same relations for SI inputs (units.hpp:148-160; usable before the base units are set)
+	float si_nu_from_si_mu(const float si_mu, const float si_rho) const { return si_mu/si_rho; }
+	float si_nu_from_si_Re(const float si_Re, const float si_x, const float si_u) const { return si_x*si_u/si_Re; }
+	float si_mu_from_si_nu(const float si_nu, const float si_rho) const { return si_nu*si_rho; }
 	float si_f_from_si_g(const float si_g, const float si_rho) const { return si_rho*si_g; }
+	float si_g_from_si_f(const float si_f, const float si_rho) const { return si_f/si_rho; }
+	float si_u_from_si_Re(const float si_Re, const float si_x, const float si_nu) const { return Relations::velocity_for_reynolds(si_Re, si_x, si_nu); }
+	float si_u_from_si_Re(const float si_Re, const float si_x, const float si_mu, const float si_rho) const { return si_Re*si_mu/(si_x*si_rho); }
+	float si_u_from_si_We(const float si_We, const float si_x, const float si_sigma, const float si_rho) const { return Relations::velocity_for_weber(si_We, si_x, si_sigma, si_rho); }
+	float si_u_from_si_Fr(const float si_Fr, const float si_x, const float si_g) const { return Relations::velocity_for_froude(si_Fr, si_x, si_g); }
+	float si_u_from_si_h(const float si_h, const float si_g) const { return sqrt(2.0f*si_h*si_g); } // speed after a free fall from height h
+	float si_u_Poiseuille_2D(const float si_Q, const float si_R) const { return Relations::poiseuille_centre_velocity_2D(si_Q, si_R); }
+	float si_u_Poiseuille_3D(const float si_Q, const float si_R) const { return Relations::poiseuille_centre_velocity_3D(si_Q, si_R); }
 };
 extern Units units; // defined in lbm.cpp (FluidX3D-master/src/lbm.cpp:3)

@@ -171,13 +171,14 @@ int lbmhip_voxelize_mesh(lbmhip_domain* domain, uint32_t direction, uint64_t t, 
                          uint32_t triangles, const float* bounding_box, const float* rotation_center, const float* linear_velocity,
                          const float* rotational_velocity);
 int lbmhip_unvoxelize_mesh(lbmhip_domain* domain, uint8_t flag, const float* bounding_box);
-/* lbmhip_voxelize_mesh for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
- * harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same arguments and results as
- * lbmhip_voxelize_mesh, but the triangles are staged in a fixed buffer inside the library's device image instead of a
- * buffer owned by the domain: no hipMalloc / hipFree, ever.  Meshes of more than LBMHIP_STATIC_MESH_TRIANGLES triangles are
- * rejected with an error.  Each GPU holds one such buffer (6.5 MiB) for the life of the process and every domain on that GPU
- * shares it: calls that overlap on one GPU (two host threads, two domains with their own streams) race; calls one after the
- * other are safe, a call only reads the triangles it has copied in itself.  Complete when the call returns. */
+/* lbmhip_voxelize_mesh for callers that cannot allocate device memory (tight serving loops, harnesses that forbid
+ * hipMalloc).  It has no counterpart in the reference.  Same arguments and results as lbmhip_voxelize_mesh, but the
+ * triangles are staged in a fixed buffer inside the library's device image instead of a buffer owned by the domain: no
+ * hipMalloc / hipFree, ever.  Meshes of more than LBMHIP_STATIC_MESH_TRIANGLES triangles are rejected with an error.  Each GPU
+ * holds one such buffer (6.5 MiB) for the life of the process and every domain on that GPU shares it: the library lets calls on
+ * one GPU take turns (a lock per GPU, held for the whole call), and a call only reads the triangles it has copied in itself.
+ * Like lbmhip_voxelize_mesh it copies from the caller's host arrays and waits for the domain's stream before it returns, so it
+ * cannot be used on a stream that is being captured into a graph. */
 #define LBMHIP_STATIC_MESH_TRIANGLES 131072u
 int lbmhip_voxelize_mesh_static(lbmhip_domain* domain, uint32_t direction, uint64_t t, uint8_t flag, const float* p0, const float* p1, const float* p2,
                                 uint32_t triangles, const float* bounding_box, const float* rotation_center, const float* linear_velocity,

@@ -1,5 +1,4 @@
-set -x
-for name in channel512_trt_sgs_fp16s channel512_trt_sgs gui512_fp16s q27_fp16c_force_slab tgv512_fp32_sgs; do
-  timeout -k 10 280 python -u tools/config_bench.py $name || exit 1
-  timeout -k 10 280 python -u tools/config_bench.py --fast-div $name || exit 1
-done
+for st in FP16S FP16C; do for tog in 1 2; do
+  echo "== $st cells together $tog"
+  SWEEP_CAPS= SWEEP_LAGS= SWEEP_BAND_ROWS=0,32 SWEEP_BAND_CAPS=0,7,6 SWEEP_BAND_LAGS=0,3,5 timeout -k 10 280 python -u tools/fused_sweep.py 512 tgv $st $tog || exit 1
+done; done
