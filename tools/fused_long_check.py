@@ -4,7 +4,8 @@ With 16-bit DDFs use about 200 steps: later on this vortex (A = 0.25) leaves the
 import sys
 import zlib
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import cfd_amd
 from cfd_amd import setups
