@@ -1,5 +1,5 @@
 """Diagnostic: per-GPU step rate of the slab runner on one GPU, the rank being its own z-neighbour over RCCL, with the steps
-taken two at a time (inner planes of both steps in one launch) and one at a time.  usage: python tools/slab_pair_bench.py [storage]"""
+taken two at a time (inner planes of both steps in one launch) and one at a time.  usage: [SLAB_ONLY_PAIRED=1] python tools/slab_pair_bench.py [storage]"""
 import ctypes as C
 import os
 import sys
@@ -33,7 +33,7 @@ def plane(z):
     return {"u": base * np.array([np.sin(c), np.sin(c), np.cos(c)], dtype=np.float32)[:, None, None]}
 
 
-for paired in (True, False, True, False):
+for paired in ((True,) if os.environ.get("SLAB_ONLY_PAIRED") else (True, False, True, False)):
     lbm = DistributedLBM((n, n, 2 * n), 0.01, storage=storage, rank=0, world=2, overlap=True, host_fields=False)
     lbm.next = lbm.prev = 0
     lbm.pair_steps = paired
