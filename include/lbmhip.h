@@ -119,19 +119,19 @@ int lbmhip_stream_collide(lbmhip_domain* domain, uint64_t t, float fx, float fy,
 int lbmhip_stream_collide_planes(lbmhip_domain* domain, uint64_t t, float fx, float fy, float fz, uint32_t z_begin, uint32_t z_end);
 /* `steps` consecutive steps t, t+1, ... with one force, nothing else happening in between: what LBM::run does per domain
  * when no exchange, force-field update or export falls between the steps (lbm.cpp:1354-1459, one stream_collide launch
- * per step there).  A single periodic domain without UPDATE_FIELDS runs them two per launch, the second step trailing
- * the first by a few lattice planes so that it reads the first step's DDFs from the Infinity Cache (same bits as
- * `steps` calls of lbmhip_stream_collide; lattices whose planes are too large for that, and every other
- * configuration, run one launch per step).  Tuning keys: "fuse" (-1 automatic, 0 never, 1 whenever possible),
- * "pair_lag", "pair_blocks_per_cu"; "fused" reads back whether the last call paired its steps.  Environment:
- * LBMHIP_FUSE=0|1. */
+ * per step there).  A domain that is not split in x or y, without UPDATE_FIELDS, may run them two per launch (same bits as
+ * `steps` calls of lbmhip_stream_collide): band by band on each XCD, the second step a few lattice planes behind the first
+ * and served by the caches instead of HBM.  Automatic for plain D3Q19 SRT on planes of at least 256 x 256 cells; every
+ * other configuration runs one launch per step unless "fuse" asks otherwise.  A paired launch never returns an error of its
+ * own: should its assumptions about workgroup placement not hold, the launch that follows it finishes the work step by
+ * step and the domain stops pairing (one line on stderr; lbmhip_get_tuning "band_given_up").  Tuning keys: lbmhip_set_tuning. */
 int lbmhip_stream_collide_steps(lbmhip_domain* domain, uint64_t t, uint32_t steps, float fx, float fy, float fz);
 /* Step t on the planes [z_begin, z_end) and step t+1 on the planes [z_begin+2, z_end-2), whose cells depend on nothing
  * outside [z_begin, z_end) (a slot and its owner are at most one plane apart, kernel.cpp:1332-1345): for the inner planes
  * of a z-slab, between the exchange of step t-1 and that of step t+1 - the caller steps the planes next to the halos by
- * lbmhip_stream_collide_planes around the exchange of step t.  One launch with the second step trailing the first where
- * lbmhip_stream_collide_steps would pair (same conditions; lbmhip_get_tuning "pairs_steps" tells beforehand, "fused"
- * afterwards), else two launches.  No counterpart
+ * lbmhip_stream_collide_planes around the exchange of step t.  One launch (plus the short one that finishes it) with the second
+ * step trailing the first where lbmhip_stream_collide_steps would pair (same conditions; lbmhip_get_tuning "pairs_steps" tells
+ * beforehand, "fused" afterwards), else two launches.  No counterpart
  * in the reference, which exchanges after every single launch (lbm.cpp:1411-1459). */
 int lbmhip_stream_collide_pair_planes(lbmhip_domain* domain, uint64_t t, float fx, float fy, float fz, uint32_t z_begin, uint32_t z_end);
 int lbmhip_update_fields(lbmhip_domain* domain, uint64_t t, float fx, float fy, float fz); /* kernel.cpp:1812-1894 */
@@ -218,12 +218,17 @@ int lbmhip_timer_stop(lbmhip_domain* domain, float* milliseconds); /* waits for 
  * times each) and the one with the best median is kept; every geometry computes the same bits.  0 = fixed defaults; the environment variable
  * LBMHIP_AUTOTUNE=0 has the same effect for every domain created afterwards).
  * Two steps per launch (lbmhip_stream_collide_steps, lbmhip_stream_collide_pair_planes): "fuse" (-1 = automatic: plain D3Q19
- * SRT on planes of at least 512 x 512 cells that fit the Infinity Cache lag+4 at a time; 0 = never; 1 = whenever a compiled
- * instance exists; LBMHIP_FUSE=0|1 sets it for every domain created afterwards), "pair_lag" (0 = automatic, 3..64: planes the
- * second step trails the first by), "pair_blocks_per_cu" (-1 = automatic, 0 = no limit), "pair_cells_together" (16-bit DDFs:
- * 1 or 2).  Read-only keys of lbmhip_get_tuning: "tuned" (the search has finished), "jit" (the last launch ran a kernel
- * compiled at run time), "pairs_steps" (two steps of this domain would share a launch), "fused" (the last
- * lbmhip_stream_collide_steps / lbmhip_stream_collide_pair_planes call did pair its steps). */
+ * SRT on planes of at least 256 x 256 cells, band by band; 0 = never; 1 = the form whose second step reads through the
+ * Infinity Cache from any XCD, whenever a compiled instance exists; 2 = band by band on each XCD, whenever a compiled
+ * instance exists; LBMHIP_FUSE=0|1|2 sets it for every domain created afterwards).  Band by band: "band_rows" (0 = automatic,
+ * 2..4096 lattice rows per band), "band_lag" (0 = automatic, 2..64: planes the second step trails the first by),
+ * "band_blocks_per_cu" (-1 = automatic, 0 = no limit), "band_spin_limit" (-1 = default; polls before a wait gives up - 0 makes
+ * every unfinished wait give up, for tests).  Form 1: "pair_lag" (0 = automatic, 3..64), "pair_blocks_per_cu".  Both:
+ * "pair_cells_together" (16-bit DDFs: 1 or 2), "pair_block" (0 = automatic, 64..256 lanes per workgroup).
+ * Read-only keys of lbmhip_get_tuning: "tuned" (the search has finished), "jit" (the last launch ran a kernel
+ * compiled at run time), "pairs_steps" (two steps of this domain would share a launch), "fused" (what the last
+ * lbmhip_stream_collide_steps / lbmhip_stream_collide_pair_planes call did: 0 = a launch per step, 1 or 2 = the form it
+ * paired its steps in), "band_given_up" (paired launches found to have given up waits; their work was redone). */
 int lbmhip_set_tuning(lbmhip_domain* domain, const char* key, int value);
 /* Reads back a launch setting ("cells_per_thread", "cells_together", "blocks_per_cu", "block", "autotune"), "tuned" (1 once
  * the geometry search has finished; the launch settings then report its choice) or "jit" (1 when the last stream_collide
