@@ -240,7 +240,7 @@ def main():
         return n, seconds, per_rank, ms_events.value, geometry, overlap
 
     def roofline(storage, n, ms_events, geometry, workload):
-        """Algorithmic bytes of a launch (SURVEY byte model x cells x steps per launch) over the time of a launch between HIP events."""
+        """Algorithmic bytes of a launch (the reference's bytes per cell and step, lbm.cpp:51-82, x cells x steps per launch) over the time of a launch between HIP events."""
         B = lib.lbmhip_bandwidth_bytes_per_cell(cfg["Q"], STORAGE[storage], feature_mask(cfg["features"]))
         cells_rank = n[0] * n[1] * (n[2] // world)
         spl = geometry["steps_per_launch"]
