@@ -179,6 +179,19 @@ template <> struct Store<ST_FP16S> {
 		asm("v_fma_mixlo_f16 %0, %1, %2, neg(0)" : "=v"(r) : "v"(x), "s"(32768.0f));
 		return (raw)r;
 	}
+	// One of the two DDFs of a dword (h = 0: low half, 1: high half) without taking the dword apart.  decode_half is the
+	// conversion and the scaling in one instruction (the product of a half and 2^-15 is exact before its one rounding, the
+	// addend -0 leaves it as it is); encode_half is encode() writing its half of w in place and keeping the other half.
+	static __device__ __forceinline__ float decode_half(uint32_t w, int h) {
+		float r;
+		if (h == 0) asm("v_fma_mix_f32 %0, %1, %2, neg(0) op_sel_hi:[1,0,0]" : "=v"(r) : "v"(w), "s"(3.0517578E-5f));
+		else asm("v_fma_mix_f32 %0, %1, %2, neg(0) op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(w), "s"(3.0517578E-5f));
+		return r;
+	}
+	static __device__ __forceinline__ void encode_half(uint32_t& w, int h, float x) {
+		if (h == 0) asm("v_fma_mixlo_f16 %0, %1, %2, neg(0)" : "+v"(w) : "v"(x), "s"(32768.0f));
+		else asm("v_fma_mixhi_f16 %0, %1, %2, neg(0)" : "+v"(w) : "v"(x), "s"(32768.0f));
+	}
 	// two neighbouring cells at once: one dword, the first cell in its low half; conversion with v_cvt_pk_f16_f32 (round to nearest even)
 	typedef uint32_t raw2;
 	static __device__ __forceinline__ float2v decode2(raw2 r) { return __builtin_convertvector(__builtin_bit_cast(half2v, r), float2v)*3.0517578E-5f; }

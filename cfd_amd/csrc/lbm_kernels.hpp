@@ -292,19 +292,27 @@ __device__ __forceinline__ void collide_row_wide(const Args& a, const uint32_t c
 				const uint32_t xv = x+(uint32_t)v;
 				const uint8_t bo = fl[v]&TYPE_BO;
 				float f[Q];
-				static_for<0, Q, 1>([&](auto I) { f[I] = S::decode(d[I][v]); });
+				constexpr bool halves = ST == ST_FP16S; // the two DDFs of a dword are decoded from it and encoded into it in place
+				if constexpr (halves) static_for<0, Q, 1>([&](auto I) { f[I] = S::decode_half(pair_of<uint32_t, V>(d[I], v&~1), v&1); });
+				else static_for<0, Q, 1>([&](auto I) { f[I] = S::decode(d[I][v]); });
 				if (feat(F_MOVING_BOUNDARIES) && bo == TYPE_MS) apply_moving_boundaries<Q>(f, a, xv, yq, zq);
 				float rhon, uxn, uyn, uzn;
 				collide<Q, COLL, FO>(f, feat, &bo, a, row0, xv, rhon, uxn, uyn, uzn, &wf[v]);
 				if (FO || feat(F_UPDATE_FIELDS)) { out[0][v] = rhon; out[1][v] = uxn; out[2][v] = uyn; out[3][v] = uzn; }
 				if constexpr (!FO) { // streaming part 1 in registers: the slot that held f[i] receives f[i+1] and vice versa (kernel.cpp:1339-1345)
 					S::template prescale<Q>(f);
-					d[0][v] = S::encode_scaled(f[0]);
-					static_for<1, Q, 2>([&](auto I) {
-						constexpr int i = I;
-						d[i][v] = S::encode_scaled(f[i+1]);
-						d[i+1][v] = S::encode_scaled(f[i]);
-					});
+					if constexpr (halves) {
+						auto put = [&](rvec& into, const float value) { uint32_t w = pair_of<uint32_t, V>(into, v&~1); S::encode_half(w, v&1, value); set_pair<uint32_t, V>(into, v&~1, w); };
+						put(d[0], f[0]);
+						static_for<1, Q, 2>([&](auto I) { constexpr int i = I; put(d[i], f[i+1]); put(d[i+1], f[i]); });
+					} else {
+						d[0][v] = S::encode_scaled(f[0]);
+						static_for<1, Q, 2>([&](auto I) {
+							constexpr int i = I;
+							d[i][v] = S::encode_scaled(f[i+1]);
+							d[i+1][v] = S::encode_scaled(f[i]);
+						});
+					}
 				}
 			}
 		} else {
@@ -585,7 +593,7 @@ __global__ __launch_bounds__(256, (P == 2 && V == 2 ? 3 : 1)) void k_collide_pai
 			}
 			if (lane == 0u) {
 				give_up = failed ? 1u : 0u;
-				if (failed) p.redo[__hip_atomic_fetch_add(p.redo_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = ((uint64_t)z*a.Ny+y)*a.xchunks+chunk;
+				if (failed) p.redo[__hip_atomic_fetch_add(p.redo_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = (((uint64_t)a.Nz+z)*a.Ny+y)*a.xchunks+chunk; // a task of step t+1
 			}
 		}
 		__syncthreads();
@@ -600,7 +608,7 @@ __global__ __launch_bounds__(256, (P == 2 && V == 2 ? 3 : 1)) void k_collide_pai
 	}
 }
 
-// ---------------------------------------------------------------------------------------------- two time steps in one launch, band by band on each XCD
+// ---------------------------------------------------------------------------------------------- two (to four) time steps in one launch, band by band on each XCD
 // k_collide_band is the second form of two steps per launch: step t+1 finds what step t wrote in the L2 of its own XCD (4 MiB)
 // instead of in the Infinity Cache, and what it writes over those lines leaves the L2 once instead of twice.
 //   Which cells depend on which: between two consecutive steps the owner of a DDF slot moves by exactly one c_i (stream i at
@@ -626,52 +634,54 @@ __global__ __launch_bounds__(256, (P == 2 && V == 2 ? 3 : 1)) void k_collide_pai
 //   and gives up too.  k_collide_seam runs the tasks of the list (step t is complete by then and nothing in the launch depends
 //   on step t+1), so the lattice is right in every case and only time is lost; the host turns the pairing off when it finds
 //   *error set.
+//   More than two steps (BandArgs::steps, up to 4) go the same way: step t+s takes the band's rows shifted down by s, trails
+//   step t+s-1 by `lag` planes, waits for that step's stamps and leaves stamps of its own; s rows at either edge of a block are
+//   left to the s-th k_collide_seam launch, and a task that gives up leaves no stamp, so the tasks that need it give up too.
+//   512^3 FP32: 3 steps 85.9-87.8 %, 4 steps 82.9-85.3 % of 8 TB/s where 2 steps reach 88.3-89.3 % - the second step's
+//   reads already come from a cache, further steps only add waits and seam rows - so the host asks for 2 unless told otherwise.
 struct BandArgs {
-	uint32_t* stamps;      // [8 blocks][bands][Nz][R][xchunks]: (launch number << 3 | XCD) of every finished step-t task; never cleared, launch numbers rise
+	uint32_t* stamps;      // [steps-1][8 blocks][bands][Nz][R][xchunks]: (launch number << 3 | XCD) of every finished task of a step that another step of the launch follows; never cleared, launch numbers rise
+	uint64_t stamps_per_step;
 	uint32_t stamp;        // this launch's number << 3
 	uint32_t* error;       // raised by a wait that ran out (zeroed before the launch)
-	uint32_t* redo_count;  // tasks of step t+1 given up (zeroed before the launch)
-	uint64_t* redo;        // their (z*Ny+y)*xchunks+chunk
+	uint32_t* redo_count;  // tasks given up (zeroed before the launch)
+	uint64_t* redo;        // their ((step*Nz+z)*Ny+y)*xchunks+chunk
 	uint32_t block_rows;   // rows per XCD block
 	uint32_t R, bands;     // rows per band, bands per block
-	uint32_t lag;          // >= 2: step t+1 on plane first2+j follows step t on plane first2+j+lag-1
+	uint32_t lag;          // >= 2: step t+s on plane u is dispatched lag-1 planes behind step t+s-1 on plane u+1
 	uint32_t spin_limit;   // polls before a wait gives up
-	uint32_t first1, count1, first2, count2; // planes of step t and of step t+1 (modulo Nz), as in PairArgs but first2 >= first1+1 suffices
+	uint32_t steps;        // 2..4 time steps in the launch
+	uint32_t first[4], count[4]; // planes of step t+s: first[s] .. first[s]+count[s]-1 modulo Nz, first[s] >= first[s-1]+1 (not reduced modulo Nz)
 };
 #ifndef LBM_BAND_EXP
-#define LBM_BAND_EXP 0 // diagnostic builds (tools/band_variants.sh): 1 no waits, 2 plain loads in step t+1, 4 write-through stores in step t, 32 wait statistics - 1 gives wrong lattices
+#define LBM_BAND_EXP 0 // diagnostic builds (tools/band_variants.sh): 1 no waits, 2 plain loads in the later steps, 4 write-through stores in step t, 32 wait statistics - 1 gives wrong lattices
 #endif
 __device__ __forceinline__ uint32_t xcd_of_this_wave() { uint32_t x; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(x)); return x&7u; }
+#ifndef LBM_BAND_P2_BLOCKS
+#define LBM_BAND_P2_BLOCKS 3 // workgroups per CU the register allocation of the two-cells-together instances aims at (diagnostic builds: 5 = 88 registers, 6 spills)
+#endif
 template <int Q, int ST, int COLL, int FEAT, int V = 1, int P = 1>
-__global__ __launch_bounds__(256, (P == 2 && V == 2 ? 3 : 1)) void k_collide_band(const Args a, const BandArgs p) {
+__global__ __launch_bounds__(256, (P == 2 && V == 2 ? LBM_BAND_P2_BLOCKS : 1)) void k_collide_band(const Args a, const BandArgs p) {
 	__shared__ uint32_t give_up;
-	const uint32_t Nz = a.Nz, block_of = blockIdx.x&7u, within = blockIdx.x>>3, task = blockIdx.y, band = blockIdx.z; // grid = (8*R*xchunks, count1+count2, bands)
+	const uint32_t Nz = a.Nz, block_of = blockIdx.x&7u, within = blockIdx.x>>3, band = blockIdx.z; // grid = (8*R*xchunks, plane times * steps, bands)
 	const uint32_t bs = block_of*p.block_rows, be = min(bs+p.block_rows, a.Ny); // this block's rows
 	const uint32_t b0 = bs+band*p.R, b1 = min(b0+p.R, be);                        // this band's rows
 	if (bs >= a.Ny || b0 >= be) return;
-	const uint32_t ahead = min(p.count1, p.first2+p.lag-p.first1), both = min(p.count1-ahead, p.count2);
-	uint32_t z, second = 0u;
-	if (task < ahead) z = p.first1+task;
-	else if (task < ahead+2u*both) { const uint32_t k = task-ahead; second = (k&1u)^1u; z = second ? p.first2+k/2u : p.first1+ahead+k/2u; }
-	else if (ahead+both < p.count1) z = p.first1+ahead+both+(task-ahead-2u*both);
-	else { second = 1u; z = p.first2+both+(task-ahead-2u*both); }
-	if (z >= Nz) z -= Nz;
+	// plane time tau: step t+s works on plane first[0]+tau-s*lag, the latest step first
+	const uint32_t tau = blockIdx.y/p.steps, s = p.steps-1u-blockIdx.y%p.steps;
+	const int j = (int)tau-(int)(s*p.lag)-(int)(p.first[s]-p.first[0]);
+	if (j < 0 || j >= (int)p.count[s]) return;
+	const uint32_t z = (p.first[s]+(uint32_t)j)%Nz;
 	const uint32_t chunk = within%a.xchunks, row = within/a.xchunks, xcd = xcd_of_this_wave();
-	if (!second) {
-		const uint32_t y = b0+row;
-		if (y >= b1) return;
-		__builtin_amdgcn_s_setprio(2); // step t is what step t+1 waits for
+	// step t+s takes the band's rows shifted down by s; s rows at either edge of the block are not this launch's
+	if (b0+row >= b1 || b0+row < bs+2u*s) return; // bs+s <= y; y < be-s follows from b1 <= be
+	const uint32_t y = b0+row-s;
+	if (s == 0u) {
+		__builtin_amdgcn_s_setprio(2); // step t is what the other steps wait for
 		constexpr int MEM1 = (LBM_BAND_EXP&4) ? MEM_STORE_THROUGH : MEM_PLAIN;
 		if constexpr (V == 1) collide_row<Q, ST, COLL, FEAT, false, MEM1>(a, chunk, y, z);
 		else collide_row_wide<Q, ST, COLL, FEAT, V, P, false, MEM1>(a, chunk, y, z);
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's stores have been acknowledged by the L2
-		__syncthreads();
-		if (threadIdx.x == 0u) *(volatile uint32_t*)(p.stamps+((((uint64_t)block_of*p.bands+band)*Nz+z)*p.R+row)*a.xchunks+chunk) = p.stamp|xcd;
 	} else {
-		// rows b0-1 .. b1-2; the block's first row and the row above it, and the block's last row, are not this launch's
-		const uint32_t lo = band == 0u ? bs+1u : max(b0-1u, bs+1u), hi = b1 == be ? be-1u : b1-1u;
-		if (b0+row < lo+1u || b0+row-1u >= hi) return;
-		const uint32_t y = b0+row-1u;
 		const uint32_t x = (chunk*blockDim.x+threadIdx.x)*(uint32_t)V;
 		uint32_t early = 0u;
 		if (x < a.Nx) early = ld<uint8_t>(a.flags+((uint64_t)z*a.Ny+y)*a.Nx, x); // flags are never written by a step
@@ -679,12 +689,11 @@ __global__ __launch_bounds__(256, (P == 2 && V == 2 ? 3 : 1)) void k_collide_ban
 			// lane = (plane z-1..z+1) * 9 + (row y-1..y+1) * 3 + (chunk-1..chunk+1, periodic; the same chunk twice in short rows is harmless)
 			const uint32_t lane = threadIdx.x, dz = lane/9u, dr = (lane/3u)%3u, dc = lane%3u;
 			const uint32_t zz = (z+Nz-1u+(lane < 27u ? dz : 0u))%Nz;
-			const bool asked = lane < 27u && (zz+Nz-p.first1)%Nz < p.count1; // planes outside this launch's step t were finished by earlier launches
-			uint32_t bb = (y-1u-bs)/p.R, rr = (y-1u-bs)%p.R+dr; // the rows y-1..y+1 lie inside the block: bs < y < be-1
-			if (rr >= p.R) { rr -= p.R; bb++; }
-			if (rr >= p.R) { rr -= p.R; bb++; } // bands of two rows
+			const bool asked = lane < 27u && (zz+Nz-p.first[s-1u]%Nz)%Nz < p.count[s-1u]; // planes outside this launch's step t+s-1 were finished by earlier launches
+			// step t+s-1 did row y' as row y'+s-1 of the block's bands; y-1 >= bs+s-1 and y+1 < be-s+1 lie inside what it did
+			const uint32_t at = y-1u+(s-1u)-bs+dr, bb = at/p.R, rr = at%p.R;
 			const uint32_t cc = (chunk+a.xchunks+dc-1u)%a.xchunks;
-			const uint32_t* const word = lane == 27u ? p.error : p.stamps+((((uint64_t)block_of*p.bands+bb)*Nz+zz)*p.R+rr)*a.xchunks+cc;
+			const uint32_t* const word = lane == 27u ? p.error : p.stamps+(s-1u)*p.stamps_per_step+((((uint64_t)block_of*p.bands+bb)*Nz+zz)*p.R+rr)*a.xchunks+cc;
 			const uint32_t want = p.stamp|xcd;
 			bool failed = false;
 #if LBM_BAND_EXP&32
@@ -707,7 +716,7 @@ __global__ __launch_bounds__(256, (P == 2 && V == 2 ? 3 : 1)) void k_collide_ban
 				if (spins < 2u) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(127);
 			}
 #if LBM_BAND_EXP&32
-			if (lane == 0u) { // header words 4..: step-t+1 workgroups, polls, workgroups that polled more than once / more than three times, cycles between the first poll and the last
+			if (lane == 0u) { // header words 4..: waiting workgroups, polls, workgroups that polled more than once / more than three times, cycles between the first poll and the last
 				__hip_atomic_fetch_add(p.error+4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				__hip_atomic_fetch_add(p.error+5, polls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				if (polls > 1u) __hip_atomic_fetch_add(p.error+6, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -717,13 +726,14 @@ __global__ __launch_bounds__(256, (P == 2 && V == 2 ? 3 : 1)) void k_collide_ban
 #endif
 			if (lane == 0u) {
 				give_up = failed ? 1u : 0u;
-				if (failed) p.redo[__hip_atomic_fetch_add(p.redo_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = ((uint64_t)z*a.Ny+y)*a.xchunks+chunk;
+				if (failed) p.redo[__hip_atomic_fetch_add(p.redo_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = (((uint64_t)s*Nz+z)*a.Ny+y)*a.xchunks+chunk;
 			}
 		}
 		__syncthreads();
-		if (give_up) return;
+		if (give_up) return; // without a stamp: the tasks that depend on this one give up as well
+		if (s+1u < p.steps) __builtin_amdgcn_s_setprio(2);
 		Args b = a;
-		b.odd = a.odd^1u;
+		b.odd = a.odd^(s&1u);
 		constexpr int MEM2 = (LBM_BAND_EXP&2) ? MEM_PLAIN : MEM_LOAD_COHERENT;
 		if constexpr (V == 1) collide_row<Q, ST, COLL, FEAT, false, MEM2, true>(b, chunk, y, z, early);
 		else {
@@ -731,23 +741,27 @@ __global__ __launch_bounds__(256, (P == 2 && V == 2 ? 3 : 1)) void k_collide_ban
 			collide_row_wide<Q, ST, COLL, FEAT, V, P, false, MEM2>(b, chunk, y, z);
 		}
 	}
+	if (s+1u < p.steps) {
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's stores have been acknowledged by the L2
+		__syncthreads();
+		if (threadIdx.x == 0u) *(volatile uint32_t*)(p.stamps+s*p.stamps_per_step+((((uint64_t)block_of*p.bands+band)*Nz+z)*p.R+row)*a.xchunks+chunk) = p.stamp|xcd;
+	}
 }
-// What k_collide_band leaves of step t+1: the rows at the edges of the XCD blocks (blockIdx.y < count2: plane first2+blockIdx.y,
-// blockIdx.x = row of the list * xchunks + chunk), and the tasks on the redo list (blockIdx.y == count2, the workgroups
-// stride over the list).  `a` is step t+1's (odd flipped by the host).  Plain accesses: a launch of its own.
+// What k_collide_band leaves of step t+s: the rows at the edges of the XCD blocks (blockIdx.y < count: plane first+blockIdx.y,
+// blockIdx.x = row of the list * xchunks + chunk), and that step's tasks on the redo list (blockIdx.y == count, the workgroups
+// stride over the list).  `a` is step t+s's (odd set by the host).  Plain accesses: a launch of its own, one per step, in order.
 struct SeamArgs {
-	uint32_t rows[16], nrows;
-	uint32_t first2, count2;
+	uint32_t rows[64], nrows;
+	uint32_t first, count, step;
 	const uint32_t* redo_count;
 	const uint64_t* redo;
 };
 template <int Q, int ST, int COLL, int FEAT, int V = 1, int P = 1>
 __global__ __launch_bounds__(256, (P == 2 && V == 2 ? 3 : 1)) void k_collide_seam(const Args a, const SeamArgs p) {
-	if (blockIdx.y < p.count2) {
+	if (blockIdx.y < p.count) {
 		const uint32_t row = blockIdx.x/a.xchunks, chunk = blockIdx.x%a.xchunks;
 		if (row >= p.nrows) return;
-		uint32_t z = p.first2+blockIdx.y;
-		if (z >= a.Nz) z -= a.Nz;
+		const uint32_t z = (p.first+blockIdx.y)%a.Nz;
 		if constexpr (V == 1) collide_row<Q, ST, COLL, FEAT, false>(a, chunk, p.rows[row], z);
 		else collide_row_wide<Q, ST, COLL, FEAT, V, P>(a, chunk, p.rows[row], z);
 	} else {
@@ -756,8 +770,10 @@ __global__ __launch_bounds__(256, (P == 2 && V == 2 ? 3 : 1)) void k_collide_sea
 			const uint64_t e = p.redo[k];
 			const uint32_t chunk = (uint32_t)(e%a.xchunks);
 			const uint64_t zy = e/a.xchunks;
-			if constexpr (V == 1) collide_row<Q, ST, COLL, FEAT, false>(a, chunk, (uint32_t)(zy%a.Ny), (uint32_t)(zy/a.Ny));
-			else collide_row_wide<Q, ST, COLL, FEAT, V, P>(a, chunk, (uint32_t)(zy%a.Ny), (uint32_t)(zy/a.Ny));
+			const uint32_t y = (uint32_t)(zy%a.Ny), sz = (uint32_t)(zy/a.Ny);
+			if (sz/a.Nz != p.step) continue;
+			if constexpr (V == 1) collide_row<Q, ST, COLL, FEAT, false>(a, chunk, y, sz%a.Nz);
+			else collide_row_wide<Q, ST, COLL, FEAT, V, P>(a, chunk, y, sz%a.Nz);
 		}
 	}
 }

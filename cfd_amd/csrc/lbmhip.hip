@@ -60,6 +60,7 @@ struct lbmhip_domain {
 	uint32_t* band_sync; uint64_t band_sync_words; uint64_t* band_redo; uint64_t band_redo_capacity;
 	int band_rows, band_lag, band_blocks_per_cu; // rows per band, lag in planes, residency cap: 0 / 0 / -1 = automatic
 	int band_spin_limit, band_used_rows;
+	int band_steps, band_used_steps;                // time steps per k_collide_band launch: 0 = automatic, 2..4
 	uint32_t band_launches; // number of the last k_collide_band launch (the stamp its workgroups leave)
 	int band_unchecked, band_given_up;            // launches since the error word was last read; launches found to have given up waits (their tasks were redone)
 	int compute_units;
@@ -281,7 +282,7 @@ int lbmhip_domain_create(const lbmhip_config* c, lbmhip_domain** out) {
 	}
 	e = hipMalloc(&d->partial, kObjectSumBlocks*4u*sizeof(float));
 	d->fuse = -1; d->pair_lag = 0; d->pair_blocks_per_cu = -1; d->pair_cells_together = 1;
-	d->band_rows = 0; d->band_lag = 0; d->band_blocks_per_cu = -1; d->band_spin_limit = -1;
+	d->band_rows = 0; d->band_lag = 0; d->band_blocks_per_cu = -1; d->band_spin_limit = -1; d->band_steps = 0; d->band_used_steps = 0;
 	{ const char* env = getenv("LBMHIP_FUSE"); if (env && env[0] >= '0' && env[0] <= '2' && !env[1]) d->fuse = env[0]-'0'; }
 	if (e == hipSuccess) e = hipDeviceGetAttribute(&d->compute_units, hipDeviceAttributeMultiprocessorCount, c->device);
 	if (e == hipSuccess && c->Dx == 1u && c->Dy == 1u && c->Nz >= 8u) { // what k_collide_pair needs, whether or not it is ever used (264 KB at 512 planes)
@@ -456,6 +457,7 @@ int lbmhip_set_tuning(lbmhip_domain* d, const char* key, int value) {
 	if (!strcmp(key, "band_rows")) { NEED(value == 0 || (value >= 2 && value <= 4096), "band_rows must be 0 (auto) or 2..4096"); d->band_rows = value; return 0; }
 	if (!strcmp(key, "band_lag")) { NEED(value == 0 || (value >= 2 && value <= 64), "band_lag must be 0 (auto) or 2..64"); d->band_lag = value; return 0; }
 	if (!strcmp(key, "band_blocks_per_cu")) { NEED(value >= -1 && value <= 32, "band_blocks_per_cu must be -1 (auto), 0 (no limit) or 1..32"); d->band_blocks_per_cu = value; return 0; }
+	if (!strcmp(key, "band_steps")) { NEED(value == 0 || (value >= 2 && value <= 4), "band_steps must be 0 (auto) or 2..4"); d->band_steps = value; return 0; }
 	if (!strcmp(key, "band_spin_limit")) { NEED(value >= -1, "band_spin_limit must be -1 (default) or a number of polls"); d->band_spin_limit = value; return 0; }
 	if (!strcmp(key, "pair_lag")) { NEED(value == 0 || (value >= 3 && value <= 64), "pair_lag must be 0 (auto) or 3..64"); d->pair_lag = value; return 0; }
 	if (!strcmp(key, "pair_cells_together")) { NEED(value == 1 || value == 2, "pair_cells_together must be 1 or 2"); d->pair_cells_together = value; return 0; }
@@ -477,6 +479,7 @@ int lbmhip_get_tuning(lbmhip_domain* d, const char* key, int* value) {
 	if (!strcmp(key, "band_rows")) { *value = d->pair_used == 2 ? d->band_used_rows : d->band_rows; return 0; }
 	if (!strcmp(key, "band_lag")) { *value = d->pair_used == 2 ? d->pair_used_lag : d->band_lag; return 0; }
 	if (!strcmp(key, "band_blocks_per_cu")) { *value = d->pair_used == 2 ? d->pair_used_blocks_per_cu : d->band_blocks_per_cu; return 0; }
+	if (!strcmp(key, "band_steps")) { *value = d->pair_used == 2 ? d->band_used_steps : d->band_steps; return 0; }
 	if (!strcmp(key, "band_given_up")) { *value = d->band_given_up; return 0; } // two-step launches whose waits ran out (checked when the stream is synchronised)
 	if (!strcmp(key, "pair_lag")) { *value = d->pair_used ? d->pair_used_lag : d->pair_lag; return 0; }
 	if (!strcmp(key, "pair_cells_together")) { *value = d->pair_cells_together; return 0; }
@@ -635,6 +638,21 @@ template <int ST> __global__ __launch_bounds__(256) void k_convert_ddfs(const vo
 		}
 	} else { // two neighbouring values at a time, the packed forms used when a lane collides two cells together; count is even
 		typedef typename S::raw2 raw2;
+		if constexpr (ST == ST_FP16S) if (pairs == 2) { // each half of a dword on its own, converted in place (one cell after the other with two cells per lane)
+			for (uint64_t i = first; 2u*i < count; i += stride) {
+				if (to_storage) {
+					const float2v x = static_cast<const float2v*>(in)[i];
+					uint32_t w = 0xDEADBEEFu; // whichever half is written first has to survive the writing of the other
+					if (i&1u) { S::encode_half(w, 0, x.x); S::encode_half(w, 1, x.y); } else { S::encode_half(w, 1, x.y); S::encode_half(w, 0, x.x); }
+					static_cast<uint32_t*>(out)[i] = w;
+				} else {
+					const uint32_t w = static_cast<const uint32_t*>(in)[i];
+					float2v x; x.x = S::decode_half(w, 0); x.y = S::decode_half(w, 1);
+					static_cast<float2v*>(out)[i] = x;
+				}
+			}
+			return;
+		}
 		for (uint64_t i = first; 2u*i < count; i += stride) {
 			if (to_storage) static_cast<raw2*>(out)[i] = S::encode2(static_cast<const float2v*>(in)[i]);
 			else static_cast<float2v*>(out)[i] = S::decode2(static_cast<const raw2*>(in)[i]);
@@ -708,7 +726,7 @@ int lbmhip_stream_collide(lbmhip_domain* d, uint64_t t, float fx, float fy, floa
 //   fit it with room to spare (512^3 FP32: lag 4 and no cap 79.8 %, lag 3 70 %, lag 5 77 %, lag 8 65 %).
 // mode 1: k_collide_pair (step t+1 reads from the Infinity Cache, any placement of the workgroups); mode 2: k_collide_band (from the L2 of
 // the XCD, band by band, + k_collide_seam)
-struct PairPlan { PairKernels k; int mode; uint32_t lag, xchunks, block; int blocks_per_cu; uint32_t block_rows, R, bands; };
+struct PairPlan { PairKernels k; int mode; uint32_t lag, xchunks, block; int blocks_per_cu; uint32_t block_rows, R, bands, steps; };
 static bool pair_plan(const lbmhip_domain* d, PairPlan* plan) {
 	if (d->fuse == 0 || !d->pair_sync || (d->cfg.features&LBMHIP_UPDATE_FIELDS) || d->cfg.Dx != 1u || d->cfg.Dy != 1u) return false;
 	const bool half = d->cfg.storage != LBMHIP_FP32;
@@ -746,8 +764,12 @@ static bool pair_plan(const lbmhip_domain* d, PairPlan* plan) {
 		const uint32_t per_band_plane = plan->R*plan->xchunks;
 		plan->lag = d->band_lag ? (uint32_t)d->band_lag : std::max(2u, 2u+(resident+2u*per_band_plane-1u)/(2u*per_band_plane));
 		if (d->cfg.Nz < plan->lag+4u || (uint64_t)8u*per_band_plane*plan->block >= 0xFFFFFFFFull) return false;
+		// time steps per launch: every step after the first leaves one row more at either edge of a block to k_collide_seam
+		plan->steps = d->band_steps ? (uint32_t)d->band_steps : 2u;
+		while (plan->steps > 2u && plan->block_rows < 2u*plan->steps) plan->steps--; // the last step keeps two rows of a block at least
 		return true;
 	}
+	plan->steps = 2u;
 	plan->blocks_per_cu = d->pair_blocks_per_cu >= 0 ? d->pair_blocks_per_cu : 0;
 	const uint64_t resident = (uint64_t)d->compute_units*(uint64_t)(plan->blocks_per_cu > 0 ? std::min(plan->blocks_per_cu*256/(int)plan->block, per_cu_max) : per_cu_max);
 	plan->lag = d->pair_lag ? (uint32_t)d->pair_lag : std::max(3u, 2u+(uint32_t)((resident+per_plane-1u)/per_plane));
@@ -761,13 +783,14 @@ static int pairs_steps(const lbmhip_domain* d) {
 }
 static void note_pair_used(lbmhip_domain* d, const PairPlan& plan) {
 	d->pair_used = plan.mode; d->pair_used_lag = (int)plan.lag; d->pair_used_blocks_per_cu = plan.blocks_per_cu; d->band_used_rows = plan.mode == 2 ? (int)plan.R : 0;
+	d->band_used_steps = plan.mode == 2 ? (int)plan.steps : 0;
 }
 // What both forms of two steps per launch share: 64 header words (error, redo count; zeroed before every launch), behind them
 // k_collide_band's stamps (one per step-t task, never cleared: the launch numbers in them rise), and the redo list, which
 // holds every task of step t+1 at most.
 static const uint64_t kPairHeaderWords = 64u;
 static int pair_buffers(lbmhip_domain* d, uint64_t stamp_words, const PairPlan& plan) {
-	const uint64_t words = kPairHeaderWords+stamp_words, redo_capacity = (uint64_t)d->cfg.Nz*d->cfg.Ny*plan.xchunks;
+	const uint64_t words = kPairHeaderWords+stamp_words, redo_capacity = (uint64_t)(plan.steps-1u)*d->cfg.Nz*d->cfg.Ny*plan.xchunks;
 	const bool relayout = stamp_words > 0u && (words != d->band_sync_words || d->band_launches >= (1u<<28)); // another band height lays the stamps out differently
 	if (relayout || words > d->band_sync_words || redo_capacity > d->band_redo_capacity) {
 		HIP_TRY(hipStreamSynchronize(d->stream)); // an earlier launch may still use the old buffers
@@ -782,35 +805,44 @@ static int pair_buffers(lbmhip_domain* d, uint64_t stamp_words, const PairPlan& 
 	HIP_TRY(hipMemsetAsync(d->band_sync, 0, kPairHeaderWords*sizeof(uint32_t), d->stream));
 	return 0;
 }
-static int launch_collide_band_steps(lbmhip_domain* d, const PairPlan& plan, uint64_t t, float fx, float fy, float fz, uint32_t first1, uint32_t count1, uint32_t first2, uint32_t count2) {
+// `steps` (2..4) time steps in one k_collide_band launch; step t+s covers the planes first[s] .. first[s]+count[s]-1 (modulo Nz).
+// Behind it one k_collide_seam launch per later step, in order: the rows the XCD blocks leave at their edges (s at either edge for
+// step t+s: each step needs the one before on one row more) and that step's tasks on the redo list.
+static int launch_collide_band_steps(lbmhip_domain* d, const PairPlan& plan, uint64_t t, float fx, float fy, float fz, uint32_t steps, const uint32_t* first, const uint32_t* count) {
+	DeviceGuard g(d->cfg.device);
 	const uint32_t Nz = d->cfg.Nz, Ny = d->cfg.Ny;
-	if (pair_buffers(d, (uint64_t)8u*plan.bands*Nz*plan.R*plan.xchunks, plan)) return 1;
-	NEED(count1+count2 <= 65535u && plan.bands <= 65535u, "too many planes for a two-step launch (%u)", count1+count2);
+	NEED(steps >= 2u && steps <= plan.steps, "%u steps in one launch", steps);
+	const uint64_t stamps_per_step = (uint64_t)8u*plan.bands*Nz*plan.R*plan.xchunks;
+	if (pair_buffers(d, (plan.steps-1u)*stamps_per_step, plan)) return 1;
+	uint32_t plane_times = 0u;
+	for (uint32_t s = 0u; s < steps; s++) plane_times = std::max(plane_times, first[s]-first[0]+count[s]+s*plan.lag);
+	NEED(plane_times*steps <= 65535u && plan.bands <= 65535u, "too many planes for a launch of %u steps (%u)", steps, plane_times);
 	Args a = make_args(d, t, fx, fy, fz);
 	a.xchunks = plan.xchunks; a.z0 = 0u; a.z1 = Nz;
 	BandArgs p;
-	p.error = d->band_sync; p.redo_count = d->band_sync+1; p.stamps = d->band_sync+kPairHeaderWords; p.redo = d->band_redo;
+	p.error = d->band_sync; p.redo_count = d->band_sync+1; p.stamps = d->band_sync+kPairHeaderWords; p.stamps_per_step = stamps_per_step; p.redo = d->band_redo;
 	p.stamp = ++d->band_launches<<3;
 	p.block_rows = plan.block_rows; p.R = plan.R; p.bands = plan.bands; p.lag = plan.lag;
 	p.spin_limit = d->band_spin_limit >= 0 ? (uint32_t)d->band_spin_limit : 60000u; // about 0.2 s of polling (3.4 us of sleep between two polls)
-	p.first1 = first1; p.count1 = count1; p.first2 = first2; p.count2 = count2;
+	p.steps = steps;
+	for (uint32_t s = 0u; s < 4u; s++) { p.first[s] = s < steps ? first[s] : 0u; p.count[s] = s < steps ? count[s] : 0u; }
 	int blocks_per_cu = plan.blocks_per_cu;
 	if (blocks_per_cu > 0) blocks_per_cu = std::max(1, blocks_per_cu*256/(int)plan.block);
 	const uint32_t lds = blocks_per_cu > 0 ? ((160u*1024u/(uint32_t)blocks_per_cu)&~255u)-256u : 0u; // the kernel has a word of LDS of its own
-	HIP_TRY(plan.k.band(a, p, dim3(8u*plan.R*plan.xchunks, count1+count2, plan.bands), dim3(plan.block), lds, d->stream));
-	// step t+1 on the first and the last row of every block, and whatever the launch gave up
-	SeamArgs q;
-	q.nrows = 0u;
-	for (uint32_t b = 0u; b < 8u; b++) {
-		const uint32_t bs = b*plan.block_rows, be = std::min(bs+plan.block_rows, Ny);
-		if (bs >= Ny) break;
-		q.rows[q.nrows++] = bs;
-		if (be-1u > bs) q.rows[q.nrows++] = be-1u;
+	HIP_TRY(plan.k.band(a, p, dim3(8u*plan.R*plan.xchunks, plane_times*steps, plan.bands), dim3(plan.block), lds, d->stream));
+	for (uint32_t s = 1u; s < steps; s++) {
+		SeamArgs q;
+		q.nrows = 0u;
+		for (uint32_t b = 0u; b < 8u; b++) {
+			const uint32_t bs = b*plan.block_rows, be = std::min(bs+plan.block_rows, Ny);
+			if (bs >= Ny) break;
+			for (uint32_t y = bs; y < be; y++) if (y < bs+s || y+s >= be) q.rows[q.nrows++] = y; // not in [bs+s, be-s)
+		}
+		q.first = first[s]; q.count = count[s]; q.step = s; q.redo_count = p.redo_count; q.redo = p.redo;
+		Args b = make_args(d, t+s, fx, fy, fz);
+		b.xchunks = plan.xchunks; b.z0 = 0u; b.z1 = Nz;
+		HIP_TRY(plan.k.seam(b, q, dim3(q.nrows*plan.xchunks, count[s]+1u), dim3(plan.block), 0u, d->stream));
 	}
-	q.first2 = first2; q.count2 = count2; q.redo_count = p.redo_count; q.redo = p.redo;
-	Args b = make_args(d, t+1u, fx, fy, fz);
-	b.xchunks = plan.xchunks; b.z0 = 0u; b.z1 = Nz;
-	HIP_TRY(plan.k.seam(b, q, dim3(q.nrows*plan.xchunks, count2+1u), dim3(plan.block), 0u, d->stream));
 	d->band_unchecked = 1;
 	if (getenv("LBMHIP_BAND_STATS")) { // diagnostic builds with LBM_BAND_EXP&32: what the waits of this launch cost
 		uint32_t h[16];
@@ -825,7 +857,7 @@ static int launch_collide_band_steps(lbmhip_domain* d, const PairPlan& plan, uin
 static int launch_collide_pair_steps(lbmhip_domain* d, const PairPlan& plan, uint64_t t, float fx, float fy, float fz,
                                      uint32_t first1, uint32_t count1, uint32_t first2, uint32_t count2) {
 	DeviceGuard g(d->cfg.device);
-	if (plan.mode == 2) return launch_collide_band_steps(d, plan, t, fx, fy, fz, first1, count1, first2, count2);
+	if (plan.mode == 2) { const uint32_t first[2] = {first1, first2}, count[2] = {count1, count2}; return launch_collide_band_steps(d, plan, t, fx, fy, fz, 2u, first, count); }
 	if (pair_buffers(d, 0u, plan)) return 1;
 	Args a = make_args(d, t, fx, fy, fz);
 	a.xchunks = plan.xchunks; a.z0 = 0u; a.z1 = d->cfg.Nz;
@@ -841,7 +873,7 @@ static int launch_collide_pair_steps(lbmhip_domain* d, const PairPlan& plan, uin
 	HIP_TRY(plan.k.pair(a, p, dim3(plan.xchunks*d->cfg.Ny, count1+count2), dim3(plan.block), lds, d->stream));
 	// whatever the launch gave up: k_collide_seam without rows of its own
 	SeamArgs q;
-	q.nrows = 0u; q.first2 = first2; q.count2 = 0u; q.redo_count = p.redo_count; q.redo = p.redo;
+	q.nrows = 0u; q.first = first2; q.count = 0u; q.step = 1u; q.redo_count = p.redo_count; q.redo = p.redo;
 	Args b = make_args(d, t+1u, fx, fy, fz);
 	b.xchunks = plan.xchunks; b.z0 = 0u; b.z1 = d->cfg.Nz;
 	HIP_TRY(plan.k.seam(b, q, dim3(64u, 1u), dim3(plan.block), 0u, d->stream));
@@ -854,8 +886,16 @@ int lbmhip_stream_collide_steps(lbmhip_domain* d, uint64_t t, uint32_t steps, fl
 	uint32_t done = 0u;
 	d->pair_used = 0;
 	if (steps >= 2u && d->cfg.Dz == 1u && pair_plan(d, &plan)) {
-		// the whole periodic lattice: step t+1 starts behind the seam (k_collide_pair asks for the planes p-2..p+2, k_collide_band for p-1..p+1)
-		for (; steps-done >= 2u; done += 2u) { const int status = launch_collide_pair_steps(d, plan, t+done, fx, fy, fz, 0u, d->cfg.Nz, plan.mode == 2 ? 1u : 2u, d->cfg.Nz); if (status) return status; }
+		// the whole periodic lattice: every later step starts behind the seam (k_collide_pair asks for the planes p-2..p+2, k_collide_band for p-1..p+1)
+		if (plan.mode == 2) {
+			const uint32_t Nz = d->cfg.Nz, first[4] = {0u, 1u, 2u, 3u}, count[4] = {Nz, Nz, Nz, Nz};
+			while (steps-done >= 2u) {
+				const uint32_t k = std::min(steps-done, plan.steps);
+				const int status = launch_collide_band_steps(d, plan, t+done, fx, fy, fz, k, first, count);
+				if (status) return status;
+				done += k;
+			}
+		} else for (; steps-done >= 2u; done += 2u) { const int status = launch_collide_pair_steps(d, plan, t+done, fx, fy, fz, 0u, d->cfg.Nz, 2u, d->cfg.Nz); if (status) return status; }
 		note_pair_used(d, plan);
 	}
 	for (; done < steps; done++) { const int status = launch_collide_planes(d, t+done, fx, fy, fz, 0u, d->cfg.Nz, false); if (status) return status; }

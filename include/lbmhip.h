@@ -202,7 +202,8 @@ int lbmhip_object_sum(lbmhip_domain* domain, int what, uint8_t flag_marker, cons
  * applied to a HOST array on `device`, with the same device code the lattice kernels use.  to_storage != 0: in = count
  * floats, out = count stored values (float for FP32, 16-bit otherwise); to_storage == 0: the reverse.  pairs != 0 converts
  * two neighbouring values at a time with the packed instructions the kernels use when a lane collides two cells together
- * (count must be even); the results are the same.  For hosts that prepare or inspect raw DDFs, and for checking the
+ * (count must be even), pairs == 2 (FP16S) each half of a dword in place as the kernels do when a lane collides its two cells
+ * one after the other; the results are the same.  For hosts that prepare or inspect raw DDFs, and for checking the
  * conversions exhaustively.  Complete when the call returns. */
 int lbmhip_convert_ddfs(int device, uint32_t storage, int to_storage, int pairs, const void* in, void* out, uint64_t count);
 
@@ -222,7 +223,8 @@ int lbmhip_timer_stop(lbmhip_domain* domain, float* milliseconds); /* waits for 
  * Infinity Cache from any XCD, whenever a compiled instance exists; 2 = band by band on each XCD, whenever a compiled
  * instance exists; LBMHIP_FUSE=0|1|2 sets it for every domain created afterwards).  Band by band: "band_rows" (0 = automatic,
  * 2..4096 lattice rows per band), "band_lag" (0 = automatic, 2..64: planes the second step trails the first by),
- * "band_blocks_per_cu" (-1 = automatic, 0 = no limit), "band_spin_limit" (-1 = default; polls before a wait gives up - 0 makes
+ * "band_steps" (0 = automatic = 2; 2..4 time steps per launch of lbmhip_stream_collide_steps - more than two measured slower on
+ * MI355X, see lbm_kernels.hpp), "band_blocks_per_cu" (-1 = automatic, 0 = no limit), "band_spin_limit" (-1 = default; polls before a wait gives up - 0 makes
  * every unfinished wait give up, for tests).  Form 1: "pair_lag" (0 = automatic, 3..64), "pair_blocks_per_cu".  Both:
  * "pair_cells_together" (16-bit DDFs: 1 or 2), "pair_block" (0 = automatic, 64..256 lanes per workgroup).
  * Read-only keys of lbmhip_get_tuning: "tuned" (the search has finished), "jit" (the last launch ran a kernel

@@ -90,6 +90,29 @@ def test_banded_steps_equal_single_steps(gpu, kw, setup, steps, together, rows, 
         a.close(); b.close()
 
 
+@pytest.mark.parametrize("rows,lag", [(16, 2), (3, 2), (2, 3), (4, 5)])
+@pytest.mark.parametrize("per_launch", [3, 4])
+@pytest.mark.parametrize("kw,setup,steps", [(TGV, setups.taylor_green, 9), (BAND_TGV, setups.taylor_green, 7), (BAND_RAGGED, setups.channel, 8), (HALF_S, setups.taylor_green, 7), (Q27, setups.taylor_green, 6)])
+def test_three_and_four_steps_per_launch_equal_single_steps(gpu, kw, setup, steps, per_launch, rows, lag):
+    """More than two steps in one banded launch (every later step one row further down, one row more left at the block edges to the
+    launches behind), followed by a shorter launch or a single step for the rest: the bits of single launches."""
+    a = cfd_amd.LBM(**kw); b = cfd_amd.LBM(**kw)
+    try:
+        for lbm, fuse in ((a, 2), (b, 0)):
+            lbm.set_tuning("fuse", fuse)
+            setup(lbm)
+        a.set_tuning("band_rows", rows); a.set_tuning("band_lag", lag); a.set_tuning("band_steps", per_launch)
+        a.run(steps); b.run(steps)
+        blocks_of = (kw["N"][1]+7)//8
+        assert fused_flag(a) == 2 and tuning(a, "band_steps") == min(per_launch, blocks_of//2)
+        assert np.array_equal(bits(a.domains[0].download_fi()), bits(b.domains[0].download_fi())), "DDFs differ"
+        a.read_from_device(); b.read_from_device()
+        assert np.array_equal(bits(a.rho), bits(b.rho)) and np.array_equal(bits(a.u), bits(b.u))
+        assert tuning(a, "band_given_up") == 0
+    finally:
+        a.close(); b.close()
+
+
 @pytest.mark.parametrize("fuse", [1, 2])
 def test_waits_that_run_out_are_redone(gpu, fuse):
     """A wait that gives up at once (no second poll allowed, the shortest lag: the first step's workgroups are still running) leaves

@@ -61,7 +61,7 @@ def test_fp16s_both_directions(gpu):
     x = np.concatenate([rng.uniform(-2, 2, 1 << 16), rng.uniform(-1, 1, 1 << 16) * 10.0 ** rng.uniform(-12, 0, 1 << 16), want[finite]]).astype(np.float32)
     with np.errstate(over="ignore"):
         want_codes = (x * np.float32(32768.0)).astype(np.float16).view(np.uint16)
-    for pairs in (0, 1):
+    for pairs in (0, 1, 2):
         got = convert("FP16S", 0, pairs, codes, np.float32)
         assert np.array_equal(got[finite].view(np.uint32), want[finite].view(np.uint32))
         got = convert("FP16S", 1, pairs, x, np.uint16)

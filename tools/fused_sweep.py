@@ -1,7 +1,7 @@
 """Diagnostic: step rate of lbmhip_stream_collide_steps (two time steps per launch) over its lag and residency cap,
 against one launch per step.  (GPU needed)
 
-usage: [SWEEP_CAPS=0,6,4,3] [SWEEP_LAGS=3,4,5,6,7,8] [SWEEP_BAND_ROWS=8,16] [SWEEP_BAND_LAGS=0,3,4] [SWEEP_BAND_CAPS=3,4,0] [SWEEP_BAND_BLOCK=128]
+usage: [SWEEP_CAPS=0,6,4,3] [SWEEP_LAGS=3,4,5,6,7,8] [SWEEP_BAND_ROWS=8,16] [SWEEP_BAND_LAGS=0,3,4] [SWEEP_BAND_CAPS=3,4,0] [SWEEP_BAND_BLOCK=128] [SWEEP_BAND_STEPS=2,3,4]
        python tools/fused_sweep.py [n] [config: tgv|channel] [storage] [cells collided together in the paired kernel: 1|2]
 SWEEP_CAPS / SWEEP_LAGS empty: skip the sweep of k_collide_pair; SWEEP_BAND_ROWS (default empty) sweeps k_collide_band (lag 0 = automatic).
 """
@@ -66,8 +66,9 @@ lbm.set_tuning("pair_block", int(os.environ.get("SWEEP_BAND_BLOCK", "0")))  # la
 for rows in ints("SWEEP_BAND_ROWS", ""):
     for cap in ints("SWEEP_BAND_CAPS", "3,4,0"):
         for lag in ints("SWEEP_BAND_LAGS", "0,3,4,6"):
-            lbm.set_tuning("band_rows", rows); lbm.set_tuning("band_lag", lag); lbm.set_tuning("band_blocks_per_cu", cap)
-            r = rate(40)
-            print("%s %s %d^3 two steps per launch band by band, %d rows, lag %d (%d), blocks/CU<=%d: %.3f ms/step %7.0f MLUPs/s %.1f %% of 8 TB/s, given up %d" %
-                  ((config, storage, n, rows, lag, lbm.get_tuning("band_lag"), cap) + r + (lbm.get_tuning("band_given_up"),)), flush=True)
+            for k in ints("SWEEP_BAND_STEPS", "0"):
+                lbm.set_tuning("band_rows", rows); lbm.set_tuning("band_lag", lag); lbm.set_tuning("band_blocks_per_cu", cap); lbm.set_tuning("band_steps", k)
+                r = rate(48)  # 48 = 24 launches of 2, 16 of 3, 12 of 4 steps
+                print("%s %s %d^3 %d steps per launch band by band, %d rows, lag %d (%d), blocks/CU<=%d: %.3f ms/step %7.0f MLUPs/s %.1f %% of 8 TB/s, given up %d" %
+                      ((config, storage, n, lbm.get_tuning("band_steps"), rows, lag, lbm.get_tuning("band_lag"), cap) + r + (lbm.get_tuning("band_given_up"),)), flush=True)
 lbm.close()
