@@ -224,7 +224,7 @@ __device__ __forceinline__ void collide_row_wide(const Args& a, const uint32_t c
 	const uint32_t xb = x*RB, xhib = x_hi*RB, xlob = x_lo*RB; // byte offsets inside a row
 	rvec d[Q];
 	raw seam[Q];
-	static_for<0, Q, 1>([&](auto I) { d[I] = rvec(0); seam[I] = 0; });
+	static_for<0, Q, 1>([&](auto I) { seam[I] = 0; });
 	// wave-uniform row bases, formed once before the first load (with the scalar arithmetic out of the way loads and stores
 	// issue back to back): pa[0] and pa[i] the lanes' own row in the streams they own, pa[i+1] the row that holds the +c_i
 	// neighbours in the slot stream of pair (i, i+1)
@@ -240,15 +240,15 @@ __device__ __forceinline__ void collide_row_wide(const Args& a, const uint32_t c
 	auto neighbour_row = [&](auto I) -> raw* { return pa[I+1]; };
 	// Every group of accesses sits in one basic block together with its own copy of the lane offset (fresh): the
 	// instruction selector then forms each address from a scalar base and that 32-bit offset, with no vector arithmetic.
+	{ // lanes past the row end load the row's first vector (and use nothing of it): no registers to clear, no branch around the loads
+		const uint32_t o = fresh(inrow ? xb : 0u);
+		d[0] = ld_ddf<rvec, MEM>(pa[0], o);
+		static_for<1, Q, 2>([&](auto I) {
+			d[I] = ld_ddf<rvec, MEM>(own_row(I), o);
+			d[I+1] = ld_ddf<rvec, MEM>(neighbour_row(I), o); // cells x..x+V-1 of the neighbour row; shifted below when cx != 0
+		});
+	}
 	if (inrow) {
-		{
-			const uint32_t o = fresh(xb);
-			d[0] = ld_ddf<rvec, MEM>(pa[0], o);
-			static_for<1, Q, 2>([&](auto I) {
-				d[I] = ld_ddf<rvec, MEM>(own_row(I), o);
-				d[I+1] = ld_ddf<rvec, MEM>(neighbour_row(I), o); // cells x..x+V-1 of the neighbour row; shifted below when cx != 0
-			});
-		}
 		if (seam_hi) {
 			const uint32_t o = fresh(xhib);
 			static_for<1, Q, 2>([&](auto I) { if constexpr (dir<Q>(I,0) > 0) seam[I+1] = ld_ddf<raw, MEM>(neighbour_row(I), o); });
