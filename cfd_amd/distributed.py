@@ -6,6 +6,11 @@ reference swaps host pointers between domains that live in one process; here eve
 backend is "nccl", which is RCCL on ROCm).  There is no collective on the data path, only point-to-point
 exchanges with at most two peers per rank; the periodic wrap connects the last rank with rank 0.
 
+D=(Dx, Dy, Dz) with Dx*Dy*Dz ranks splits the lattice into blocks as the reference does (lbm.cpp:1038-1073, rank =
+x+(y+z*Dy)*Dx): the exchange then runs axis after axis, x, y, z, each face including the halo cells of the axes
+before it, so edges and corners arrive in two or three hops (lbm.cpp:2162-2181).  Blocks step in the reference's own
+order (whole domain, then the exchange); the overlapped and the two-steps-per-launch schedules below are for slabs.
+
 Per time step (overlapped order):
   1. the communication stream waits for the previous step
   2. stream_collide on the two lattice planes next to the halos, pack -> send/recv -> unpack   (communication stream)
@@ -33,7 +38,7 @@ WHAT = {"fi": L.HALO_FI, "rho_u_flags": L.HALO_RHO_U_FLAGS, "flags": L.HALO_FLAG
 
 class SlabOps:
     """What DistributedLBM needs from the engine that owns this rank's slab."""
-    local = (0, 0, 0)          # local lattice size including the two z halo planes
+    local = (0, 0, 0)          # local lattice size including the halo layers of every split axis
     buffers = None             # dict send_p, send_m, recv_p, recv_m -> 1-D uint8 torch tensors
     def upload(self, rho, u, flags, F): raise NotImplementedError
     def upload_plane(self, name, z_local, a): raise NotImplementedError
@@ -49,9 +54,9 @@ class SlabOps:
             self.collide_planes(t + k, f, 0, self.local[2])
     def update_fields(self, t, f): raise NotImplementedError
     def update_force_field(self, t): raise NotImplementedError
-    def pack(self, what, t): raise NotImplementedError
-    def unpack(self, what, t): raise NotImplementedError
-    def halo_bytes(self, what): raise NotImplementedError
+    def pack(self, what, t, axis=2): raise NotImplementedError
+    def unpack(self, what, t, axis=2): raise NotImplementedError
+    def halo_bytes(self, what, axis=2): raise NotImplementedError
     def scope(self): return contextlib.nullcontext()  # makes the engine's compute stream the current one for the block
     def fork(self): pass       # communication stream waits for the compute stream and becomes current
     def end_fork(self): pass   # back to the compute stream
@@ -62,12 +67,15 @@ class SlabOps:
 class HipSlabOps(SlabOps):
     """The slab lives in an lbmhip domain on this rank's GPU; torch owns the staging buffers and the streams."""
 
-    def __init__(self, local, world, Q, storage, collision, features, nu, offset_z, device):
+    def __init__(self, local, world, Q, storage, collision, features, nu, offset, device):
+        """world: number of z-slabs, or (Dx, Dy, Dz); offset: global z (or (x, y, z)) of the first local cell, halo included."""
         lib = L.lib()
         self.lib = lib
         self.device = torch.device("cuda", device)
         mask = L.feature_mask(features)
-        cfg = L.Config(local[0], local[1], local[2], 1, 1, world, 0, 0, offset_z, Q, L.STORAGE[storage], L.COLLISION[collision], mask, float(nu), device)
+        D = (1, 1, int(world)) if np.isscalar(world) else tuple(int(v) for v in world)
+        offset = (0, 0, int(offset)) if np.isscalar(offset) else tuple(int(v) for v in offset)
+        cfg = L.Config(local[0], local[1], local[2], D[0], D[1], D[2], offset[0], offset[1], offset[2], Q, L.STORAGE[storage], L.COLLISION[collision], mask, float(nu), device)
         self.dom = L.Domain(cfg)
         self.local = tuple(local)
         self.has_F = bool(mask & L.FEATURES["FORCE_FIELD"])
@@ -75,8 +83,9 @@ class HipSlabOps(SlabOps):
         self.comm = torch.cuda.Stream(device=self.device)
         L.check(lib.lbmhip_set_stream(self.dom.h, C.c_void_p(self.compute.cuda_stream)))
         self.buffers = None
-        if world > 1:
-            cap = local[0] * local[1] * max(decomposition.halo_bytes_per_cell("fi", Q, 4 if storage == "FP32" else 2), 17)
+        if D[0] * D[1] * D[2] > 1:
+            face = max(local[(a + 1) % 3] * local[(a + 2) % 3] for a in range(3) if D[a] > 1)  # cells of the largest face that is exchanged
+            cap = face * max(decomposition.halo_bytes_per_cell("fi", Q, 4 if storage == "FP32" else 2), 17)
             self.buffers = {k: torch.empty(cap, dtype=torch.uint8, device=self.device) for k in ("send_p", "send_m", "recv_p", "recv_m")}
             b = self.buffers
             L.check(lib.lbmhip_halo_set_buffers(self.dom.h, C.c_void_p(b["send_p"].data_ptr()), C.c_void_p(b["send_m"].data_ptr()),
@@ -139,15 +148,15 @@ class HipSlabOps(SlabOps):
     def update_force_field(self, t):
         L.check(self.lib.lbmhip_update_force_field(self.dom.h, C.c_uint64(t)))
 
-    def pack(self, what, t):
-        L.check(self.lib.lbmhip_halo_pack(self.dom.h, WHAT[what], 2, C.c_uint64(t)))
+    def pack(self, what, t, axis=2):
+        L.check(self.lib.lbmhip_halo_pack(self.dom.h, WHAT[what], int(axis), C.c_uint64(t)))
 
-    def unpack(self, what, t):
-        L.check(self.lib.lbmhip_halo_unpack(self.dom.h, WHAT[what], 2, C.c_uint64(t)))
+    def unpack(self, what, t, axis=2):
+        L.check(self.lib.lbmhip_halo_unpack(self.dom.h, WHAT[what], int(axis), C.c_uint64(t)))
 
-    def halo_bytes(self, what):
+    def halo_bytes(self, what, axis=2):
         n = C.c_uint64()
-        L.check(self.lib.lbmhip_halo_bytes(self.dom.h, WHAT[what], 2, C.byref(n)))
+        L.check(self.lib.lbmhip_halo_bytes(self.dom.h, WHAT[what], int(axis), C.byref(n)))
         return n.value
 
     def scope(self):
@@ -176,49 +185,60 @@ class HipSlabOps(SlabOps):
 
 
 class DistributedLBM:
-    """This rank's slab of a global Nx x Ny x Nz lattice split into `world` z-slabs.
+    """This rank's part of a global Nx x Ny x Nz lattice: one of `world` z-slabs, or with D=(Dx, Dy, Dz) one of Dx*Dy*Dz blocks.
 
-    Host fields rho/u/flags(/F) cover the rank's own planes only ([z_local, y, x]; `origin` is their global offset),
+    Host fields rho/u/flags(/F) cover the rank's own cells only ([z, y, x] local; `origin` is their global offset),
     so setups written against N/origin/rho.shape fill them without materialising the global lattice.
-    host_fields=False keeps no host copy at all (slabs of 10^9 cells): the slab starts as the engine creates it (rho = 1,
+    host_fields=False keeps no host copy at all (slabs of 10^9 cells): the part starts as the engine creates it (rho = 1,
     everything else 0), fill_planes() writes the planes that differ, and read_from_device() is not available.
     """
 
-    def __init__(self, N, nu, Q=19, storage="FP32", collision="SRT", features=(), f=(0.0, 0.0, 0.0), rank=None, world=None, ops_factory=None, overlap=True, group=None, host_fields=True):
+    def __init__(self, N, nu, Q=19, storage="FP32", collision="SRT", features=(), f=(0.0, 0.0, 0.0), rank=None, world=None, ops_factory=None, overlap=True, group=None, host_fields=True, D=None):
         self.group = group
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
-        D = (1, 1, self.world)
+        D = (1, 1, self.world) if D is None else tuple(int(v) for v in D)
+        if D[0] * D[1] * D[2] != self.world:
+            raise ValueError("D = %r needs %d ranks, the group has %d" % (D, D[0] * D[1] * D[2], self.world))
         self.N = decomposition.rounded_size(N, D)
         self.D, self.Q, self.storage, self.collision, self.features, self.nu = D, Q, storage, collision, tuple(features), float(nu)
         self.f = tuple(float(v) for v in f)
         self.local = decomposition.local_size(self.N, D)
-        self.nz = self.N[2] // self.world
-        self.origin = (0, 0, self.rank * self.nz)
-        self.hz = 1 if self.world > 1 else 0
+        self.n = tuple(self.N[k] // D[k] for k in range(3))       # own cells per axis
+        self.nz = self.n[2]
+        self.halo = decomposition.halo(D)                         # 1 on every split axis
+        self.hz = self.halo[2]
+        coords = decomposition.domain_coordinates(self.rank, D)
+        self.origin = tuple(coords[k] * self.n[k] for k in range(3))
+        self.slabs = D[0] == 1 and D[1] == 1
+        # (next, previous) rank along every axis, periodic (lbm.cpp:2130-2132)
+        self.neighbours = [[decomposition.neighbour(self.rank, D, a, 1), decomposition.neighbour(self.rank, D, a, -1)] for a in range(3)]
         if ops_factory is None:
             dev = torch.cuda.current_device()
-            ops_factory = lambda: HipSlabOps(self.local, self.world, Q, storage, collision, features, nu, self.origin[2] - self.hz, dev)
+            offset = tuple(self.origin[k] - self.halo[k] for k in range(3))
+            ops_factory = lambda: HipSlabOps(self.local, D, Q, storage, collision, features, nu, offset, dev)
         self.ops = ops_factory()
-        Nx, Ny, _ = self.N
+        nx, ny, nz = self.n
         self.has_F = "FORCE_FIELD" in features
         self.host_fields = bool(host_fields)
         self.rho = self.u = self.flags = self.F = None
         if self.host_fields:
-            self.rho = np.ones((self.nz, Ny, Nx), dtype=np.float32)
-            self.u = np.zeros((3, self.nz, Ny, Nx), dtype=np.float32)
-            self.flags = np.zeros((self.nz, Ny, Nx), dtype=np.uint8)
-            self.F = np.zeros((3, self.nz, Ny, Nx), dtype=np.float32) if self.has_F else None
+            self.rho = np.ones((nz, ny, nx), dtype=np.float32)
+            self.u = np.zeros((3, nz, ny, nx), dtype=np.float32)
+            self.flags = np.zeros((nz, ny, nx), dtype=np.uint8)
+            self.F = np.zeros((3, nz, ny, nx), dtype=np.float32) if self.has_F else None
         self.update_fields_ext = "UPDATE_FIELDS" in features
         self.t = 0
         self.initialized = False
         self.t_last_update_fields = None
-        self.overlap = bool(overlap) and self.world > 1 and self.local[2] >= 5
+        self.overlap = bool(overlap) and self.world > 1 and self.slabs and self.local[2] >= 5
         self.pair_steps = True  # run() takes the steps of a slab two at a time (_do_two_time_steps)
-        self.next = (self.rank + 1) % self.world
-        self.prev = (self.rank - 1) % self.world
         self._host_staging = None
         self._packed_t = None  # time step of DDF faces that are packed but not yet exchanged (_do_two_time_steps)
+
+    # the z neighbours under their old names (a single rank that is its own neighbour sets both to 0)
+    next = property(lambda self: self.neighbours[2][0], lambda self, r: self.neighbours[2].__setitem__(0, r))
+    prev = property(lambda self: self.neighbours[2][1], lambda self, r: self.neighbours[2].__setitem__(1, r))
 
     def get_N(self):
         return self.N[0] * self.N[1] * self.N[2]
@@ -228,7 +248,7 @@ class DistributedLBM:
             self.ops.close()
 
     # ---- the exchange: + face to the next rank's - halo, - face to the previous rank's + halo (lbm.cpp:2162-2181)
-    def _exchange(self, nbytes):
+    def _exchange(self, nbytes, axis=2):
         b = self.ops.buffers
         backend = dist.get_backend(self.group)
         views = {k: v[:nbytes] for k, v in b.items()}
@@ -239,25 +259,28 @@ class DistributedLBM:
             h = {k: v[:nbytes] for k, v in self._host_staging.items()}
             h["send_p"].copy_(views["send_p"]); h["send_m"].copy_(views["send_m"])
             torch.cuda.current_stream().synchronize()
-            self._p2p(h)
+            self._p2p(h, axis)
             views["recv_p"].copy_(h["recv_p"]); views["recv_m"].copy_(h["recv_m"])
         else:
-            self._p2p(views)
+            self._p2p(views, axis)
 
-    def _p2p(self, v):
+    def _p2p(self, v, axis=2):
         g = self.group
         gr = (lambda r: dist.get_global_rank(g, r)) if g is not None else (lambda r: r)
-        ops = [dist.P2POp(dist.isend, v["send_p"], gr(self.next), g, tag=0), dist.P2POp(dist.isend, v["send_m"], gr(self.prev), g, tag=1),
-               dist.P2POp(dist.irecv, v["recv_m"], gr(self.prev), g, tag=0), dist.P2POp(dist.irecv, v["recv_p"], gr(self.next), g, tag=1)]
+        nxt, prv = self.neighbours[axis]
+        ops = [dist.P2POp(dist.isend, v["send_p"], gr(nxt), g, tag=0), dist.P2POp(dist.isend, v["send_m"], gr(prv), g, tag=1),
+               dist.P2POp(dist.irecv, v["recv_m"], gr(prv), g, tag=0), dist.P2POp(dist.irecv, v["recv_p"], gr(nxt), g, tag=1)]
         for req in dist.batch_isend_irecv(ops):
             req.wait()
 
     def _communicate(self, what):
         if self.world <= 1:
             return
-        self.ops.pack(what, self.t)
-        self._exchange(self.ops.halo_bytes(what))
-        self.ops.unpack(what, self.t)
+        for axis in range(3):  # x, then y with the x halos in its faces, then z with both (lbm.cpp:2162-2181)
+            if self.D[axis] > 1:
+                self.ops.pack(what, self.t, axis)
+                self._exchange(self.ops.halo_bytes(what, axis), axis)
+                self.ops.unpack(what, self.t, axis)
 
     def _finish_packed_exchange(self):
         """The exchange whose faces _do_two_time_steps packed and left for later (on the communication stream of an overlapped run)."""
@@ -274,9 +297,16 @@ class DistributedLBM:
     def fill_planes(self, plane):
         """plane(z_global) -> {"flags": [y, x], "rho": [y, x], "u": [3, y, x], "F": [3, y, x]} (any subset, or None) for every
         plane this rank owns, written straight into the slab; the halo planes follow from the exchange in initialize()."""
+        hx, hy, _ = self.halo
+        (ox, oy, _), (nx, ny, _), (Lx, Ly, _) = self.origin, self.n, self.local
         for k in range(self.nz):
             got = plane(self.origin[2] + k) or {}
             for name, a in got.items():
+                if not self.slabs:  # the rank's part of the global plane, inside a frame of halo cells that the exchange fills
+                    a = np.asarray(a)
+                    framed = np.full(a.shape[:-2] + (Ly, Lx), 1 if name == "rho" else 0, dtype=a.dtype)
+                    framed[..., hy:hy + ny, hx:hx + nx] = a[..., oy:oy + ny, ox:ox + nx]
+                    a = framed
                 self.ops.upload_plane(name, k + self.hz, a)
 
     def _initialize(self):
@@ -294,15 +324,20 @@ class DistributedLBM:
         self.initialized = True
         self.t_last_update_fields = 0 if self.update_fields_ext else None
 
+    def _interior(self):
+        """Index of the rank's own cells inside its local [z, y, x] arrays."""
+        (hx, hy, hz), (nx, ny, nz) = self.halo, self.n
+        return (slice(hz, hz + nz), slice(hy, hy + ny), slice(hx, hx + nx))
+
     def _upload_host_fields(self):
         Lx, Ly, Lz = self.local
-        hz = self.hz
-        rho = np.ones((Lz, Ly, Lx), dtype=np.float32); rho[hz:Lz - hz] = self.rho
-        u = np.zeros((3, Lz, Ly, Lx), dtype=np.float32); u[:, hz:Lz - hz] = self.u
-        flags = np.zeros((Lz, Ly, Lx), dtype=np.uint8); flags[hz:Lz - hz] = self.flags
+        own = self._interior()
+        rho = np.ones((Lz, Ly, Lx), dtype=np.float32); rho[own] = self.rho
+        u = np.zeros((3, Lz, Ly, Lx), dtype=np.float32); u[(slice(None),) + own] = self.u
+        flags = np.zeros((Lz, Ly, Lx), dtype=np.uint8); flags[own] = self.flags
         F = None
         if self.has_F:
-            F = np.zeros((3, Lz, Ly, Lx), dtype=np.float32); F[:, hz:Lz - hz] = self.F
+            F = np.zeros((3, Lz, Ly, Lx), dtype=np.float32); F[(slice(None),) + own] = self.F
         self.ops.upload(rho, u, flags, F)
 
     # ---- LBM::do_time_step (lbm.cpp:1411-1459)
@@ -406,10 +441,10 @@ class DistributedLBM:
         if self.initialized:
             self.update_fields()
         Lx, Ly, Lz = self.local
-        hz = self.hz
+        own = self._interior()
         got = self.ops.download(("rho", "u", "flags") + (("F",) if self.has_F else ()))
-        self.rho[...] = got["rho"].reshape(Lz, Ly, Lx)[hz:Lz - hz]
-        self.u[...] = got["u"].reshape(3, Lz, Ly, Lx)[:, hz:Lz - hz]
-        self.flags[...] = got["flags"].reshape(Lz, Ly, Lx)[hz:Lz - hz]
+        self.rho[...] = got["rho"].reshape(Lz, Ly, Lx)[own]
+        self.u[...] = got["u"].reshape(3, Lz, Ly, Lx)[(slice(None),) + own]
+        self.flags[...] = got["flags"].reshape(Lz, Ly, Lx)[own]
         if self.has_F:
-            self.F[...] = got["F"].reshape(3, Lz, Ly, Lx)[:, hz:Lz - hz]
+            self.F[...] = got["F"].reshape(3, Lz, Ly, Lx)[(slice(None),) + own]

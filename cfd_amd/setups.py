@@ -89,13 +89,13 @@ def channel(lbm, seed=42, u0=0.0):
     """Force-driven channel, periodic in x, solid walls in y and z, plus an obstacle mask extruded along z.
     Needs VOLUME_FORCE (the force comes from the LBM constructor)."""
     Nx, Ny, Nz = lbm.N
-    _, _, za = _axes(lbm)
+    xa, ya, za = _axes(lbm)
     lbm.rho[...] = 1.0
     lbm.u[...] = 0.0
     lbm.u[0][...] = np.float32(u0)
     mask = obstacle_mask(Nx, Ny, seed)
     for k, z in enumerate(za):
-        lbm.flags[k] = channel_flag_plane(Nx, Ny, Nz, int(z), seed, mask)
+        lbm.flags[k] = channel_flag_plane(Nx, Ny, Nz, int(z), seed, mask)[ya[0]:ya[-1] + 1, xa[0]:xa[-1] + 1]
 
 
 def inflow_box(lbm, u_in=0.075, radius_frac=0.15):
@@ -125,7 +125,7 @@ def sphere_force(lbm, u_in=0.05, radius_frac=0.2):
     lbm.rho[...] = 1.0
     lbm.u[...] = 0.0
     lbm.u[0][~solid] = np.float32(-u_in)
-    flags = np.zeros((Nz, Ny, Nx), dtype=np.uint8)
+    flags = np.zeros(x.shape, dtype=np.uint8)
     face = (x == 0) | (x == Nx - 1) | (y == 0) | (y == Ny - 1) | (z == 0) | (z == Nz - 1)
     flags[face] = TYPE_E
     flags[solid] = TYPE_S | TYPE_X

@@ -9,8 +9,11 @@ from oracle import harness as H
 
 class OracleSlabOps(SlabOps):
     def __init__(self, local, world, Q, storage, collision, features, nu):
+        """world: number of z-slabs, or (Dx, Dy, Dz)."""
         self.local = tuple(local)
-        self.engine = H.PortEngine(local, (1, 1, world), Q, storage, collision, features, nu)
+        D = (1, 1, int(world)) if np.isscalar(world) else tuple(int(v) for v in world)
+        self.D = D
+        self.engine = H.PortEngine(local, D, Q, storage, collision, features, nu)
         n = local[0] * local[1] * local[2]
         self.n, self.Q, self.storage = n, Q, storage
         self.fi = np.zeros(Q * n, dtype=np.float32 if storage == "FP32" else np.uint16)
@@ -19,9 +22,10 @@ class OracleSlabOps(SlabOps):
         self.flags = np.zeros(n, dtype=np.uint8)
         self.F = np.zeros(3 * n, dtype=np.float32) if "FORCE_FIELD" in features else None
         self.per_cell = {"fi": H.TRANSFERS[Q] * (4 if storage == "FP32" else 2), "rho_u_flags": 17, "flags": 1, "F": 12}
-        cap = local[0] * local[1] * max(self.per_cell["fi"], 17)
+        self.face = [local[(a + 1) % 3] * local[(a + 2) % 3] for a in range(3)]
+        cap = max([self.face[a] for a in range(3) if D[a] > 1] or [0]) * max(self.per_cell["fi"], 17)
         self.np_buffers = {k: np.zeros(cap, dtype=np.uint8) for k in ("send_p", "send_m", "recv_p", "recv_m")}
-        self.buffers = {k: torch.from_numpy(v) for k, v in self.np_buffers.items()} if world > 1 else None
+        self.buffers = {k: torch.from_numpy(v) for k, v in self.np_buffers.items()} if D[0] * D[1] * D[2] > 1 else None
         self.cfg = self.engine.cfg
 
     def upload(self, rho, u, flags, F):
@@ -61,13 +65,13 @@ class OracleSlabOps(SlabOps):
     def update_force_field(self, t):
         self.engine.update_force_field(self.fi, self.flags, t, self.F)
 
-    def _transfer(self, what, t, insert):
+    def _transfer(self, what, t, insert, axis):
         p = self.np_buffers["recv_p" if insert else "send_p"]
         m = self.np_buffers["recv_m" if insert else "send_m"]
-        if what == "fi": self.engine.transfer_fi(insert, 2, t, p, m, self.fi)
-        elif what == "rho_u_flags": self.engine.transfer_rho_u_flags(insert, 2, t, p, m, self.rho, self.u, self.flags)
-        elif what == "F": self.engine.transfer_F(insert, 2, t, p, m, self.F)
+        if what == "fi": self.engine.transfer_fi(insert, axis, t, p, m, self.fi)
+        elif what == "rho_u_flags": self.engine.transfer_rho_u_flags(insert, axis, t, p, m, self.rho, self.u, self.flags)
+        elif what == "F": self.engine.transfer_F(insert, axis, t, p, m, self.F)
 
-    def pack(self, what, t): self._transfer(what, t, 0)
-    def unpack(self, what, t): self._transfer(what, t, 1)
-    def halo_bytes(self, what): return self.local[0] * self.local[1] * self.per_cell[what]
+    def pack(self, what, t, axis=2): self._transfer(what, t, 0, axis)
+    def unpack(self, what, t, axis=2): self._transfer(what, t, 1, axis)
+    def halo_bytes(self, what, axis=2): return self.face[axis] * self.per_cell[what]

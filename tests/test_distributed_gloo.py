@@ -31,8 +31,9 @@ def _worker(rank, world, port, kw, setup_name, steps, overlap, out_dir):
         from cfd_amd import decomposition
         kw = dict(kw)
         N = kw.pop("N")
-        local = decomposition.local_size(decomposition.rounded_size(N, (1, 1, world)), (1, 1, world))
-        engine = lambda: OracleSlabOps(local, world, kw.get("Q", 19), kw.get("storage", "FP32"), kw.get("collision", "SRT"), kw.get("features", ()), kw["nu"])
+        D = kw.get("D") or (1, 1, world)
+        local = decomposition.local_size(decomposition.rounded_size(N, D), D)
+        engine = lambda: OracleSlabOps(local, D, kw.get("Q", 19), kw.get("storage", "FP32"), kw.get("collision", "SRT"), kw.get("features", ()), kw["nu"])
         if setup_name == "channel_planes":  # no host copy of the fields: flags go into the slab plane by plane
             lbm = DistributedLBM(N, rank=rank, world=world, overlap=overlap, ops_factory=engine, host_fields=False, **kw)
             G = lbm.N
@@ -41,8 +42,9 @@ def _worker(rank, world, port, kw, setup_name, steps, overlap, out_dir):
             lbm.update_fields()
             Lx, Ly, Lz = lbm.local
             got = lbm.ops.download(("rho", "u", "flags"))
-            np.savez(os.path.join(out_dir, "rank%d.npz" % rank), rho=got["rho"].reshape(Lz, Ly, Lx)[1:-1], u=got["u"].reshape(3, Lz, Ly, Lx)[:, 1:-1],
-                     flags=got["flags"].reshape(Lz, Ly, Lx)[1:-1])
+            zs = slice(lbm.hz, Lz - lbm.hz)
+            np.savez(os.path.join(out_dir, "rank%d.npz" % rank), rho=got["rho"].reshape(Lz, Ly, Lx)[zs], u=got["u"].reshape(3, Lz, Ly, Lx)[:, zs],
+                     flags=got["flags"].reshape(Lz, Ly, Lx)[zs])
             return
         lbm = DistributedLBM(N, rank=rank, world=world, overlap=overlap, ops_factory=engine, **kw)
         getattr(setups, setup_name)(lbm)
@@ -72,6 +74,32 @@ def test_slab_exchange_matches_single_process(tmp_path, world, overlap, setup):
         assert np.array_equal(got["flags"], ref.flags[sl])
         assert np.array_equal(got["rho"].view(np.uint32), ref.rho[sl].view(np.uint32))
         assert np.array_equal(got["u"].view(np.uint32), ref.u[:, sl].view(np.uint32))
+
+
+@pytest.mark.parametrize("D,setup", [((2, 2, 1), "channel"), ((2, 1, 2), "channel"), ((1, 2, 2), "taylor_green"), ((2, 2, 2), "channel"), ((2, 2, 1), "channel_planes_blocks")])
+def test_block_exchange_matches_single_process(tmp_path, D, setup):
+    """Dx x Dy x Dz blocks, one rank each (lbm.cpp:1038-1073): the exchange runs x, then y, then z, so that edge and corner cells
+    arrive through the halos of the axes before (lbm.cpp:2162-2181).  Every rank's block equals its part of the undivided lattice."""
+    sys.path.insert(0, ROOT)
+    from cfd_amd import setups, decomposition
+    from oracle import harness as H
+    world = D[0] * D[1] * D[2]
+    kw = dict(N=(12, 10, 8), nu=0.02, Q=19, storage="FP32", collision="SRT", features=("VOLUME_FORCE", "SUBGRID"), f=(1e-4, 2e-5, 0.0), D=D)
+    steps = 7
+    worker_setup = {"channel_planes_blocks": "channel_planes"}.get(setup, setup)
+    mp.spawn(_worker, args=(world, _free_port(), kw, worker_setup, steps, True, str(tmp_path)), nprocs=world, join=True)
+    ref = H.OracleLBM(kw["N"], kw["nu"], D=(1, 1, 1), Q=19, features=kw["features"], f=kw["f"])
+    (setups.taylor_green if setup == "taylor_green" else setups.channel)(ref)
+    ref.run(steps)
+    ref.read_from_device()
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        glob, loc = decomposition.slices(r, kw["N"], D)
+        if setup == "channel_planes_blocks":  # saved with the halo cells of x and y, without those of z
+            got = {k: got[k][..., loc[1], loc[2]] for k in ("rho", "u", "flags")}
+        assert np.array_equal(got["flags"], ref.flags[glob])
+        assert np.array_equal(got["rho"].view(np.uint32), ref.rho[glob].view(np.uint32))
+        assert np.array_equal(got["u"].view(np.uint32), ref.u[(slice(None),) + glob].view(np.uint32))
 
 
 # ---- which buffer meets which: the message pairing of the exchange for 2, 3 and 8 ranks, without any process group

@@ -61,6 +61,28 @@ def test_two_ranks_on_one_gpu_match_the_oracle(gpu, tmp_path, overlap):
         assert np.array_equal(got["u"].view(np.uint32), ref.u[:, sl].view(np.uint32))
 
 
+@pytest.mark.parametrize("D,storage", [((2, 2, 1), "FP32"), ((2, 1, 2), "FP16S"), ((2, 2, 2), "FP32")])
+def test_blocks_on_one_gpu_match_the_oracle(gpu, tmp_path, D, storage):
+    """Dx x Dy x Dz blocks, one rank each, all on this GPU (gloo, staged through the host): the HIP halo kernels of all three axes
+    under the multi-process exchange, x then y then z (lbm.cpp:2162-2181).  Every block equals its part of the oracle's lattice."""
+    sys.path.insert(0, ROOT)
+    from cfd_amd import setups, decomposition
+    from oracle import harness as H
+    world, steps = D[0] * D[1] * D[2], 9
+    kw = dict(N=(64, 24, 16), nu=0.01, Q=19, storage=storage, collision="TRT", features=("VOLUME_FORCE", "SUBGRID"), f=(1e-4, 3e-5, 0.0), D=D)
+    mp.spawn(_worker, args=(world, _free_port(), kw, steps, True, str(tmp_path)), nprocs=world, join=True)
+    ref = H.OracleLBM(kw["N"], kw["nu"], D=(1, 1, 1), Q=19, storage=storage, collision="TRT", features=kw["features"], f=kw["f"])
+    setups.channel(ref)
+    ref.run(steps)
+    ref.read_from_device()
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        glob, _ = decomposition.slices(r, kw["N"], D)
+        assert np.array_equal(got["flags"], ref.flags[glob])
+        assert np.array_equal(got["rho"].view(np.uint32), ref.rho[glob].view(np.uint32))
+        assert np.array_equal(got["u"].view(np.uint32), ref.u[(slice(None),) + glob].view(np.uint32))
+
+
 def _self_exchange_worker(rank, port, kw, steps, overlap, out_dir):
     """One rank, backend nccl (= RCCL): the rank is its own z-neighbour on both sides, so its slab with halo planes is a
     periodic lattice of nz planes.  Runs the production exchange code (device buffers, RCCL send/recv, streams)."""
