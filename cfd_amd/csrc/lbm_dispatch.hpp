@@ -45,7 +45,7 @@ hipError_t launch_collide_seam(const Args& a, const SeamArgs& p, dim3 grid, dim3
 	hipLaunchKernelGGL((k_collide_seam<Q, ST, COLL, FEAT, V, P>), grid, block, lds_bytes, stream, a, p);
 	return hipGetLastError();
 }
-struct PairKernels { pair_launch_fn pair; band_launch_fn band; seam_launch_fn seam; };
+struct PairKernels { pair_launch_fn pair; band_launch_fn band; seam_launch_fn seam; bool pays; }; // pays: measured faster than a launch per step on MI355X (512^3, moving field) - what automatic mode goes by
 PairKernels select_collide_pair(int Q, int ST, int COLL, int FEAT, int V, int P); // V = 1 (FP32 DDFs) or 2 (16-bit DDFs); all null without an instance
 
 // FEAT < 0 selects the instance that reads the feature mask at run time; FO = update_fields (always run-time features)

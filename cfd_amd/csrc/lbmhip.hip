@@ -721,7 +721,9 @@ int lbmhip_stream_collide(lbmhip_domain* d, uint64_t t, float fx, float fy, floa
 //   a band.  Best with 32 tasks per plane of a band, no residency cap and the lag that lets step t's workgroups leave before
 //   step t+1 asks for them (6 planes at 32 tasks); shorter lags wait, caps cost more bandwidth than the L2 hits return.
 //   The TRT + subgrid channel kernel (132 registers, 3 workgroups per CU) loses to single launches in either form (65 against
-//   72 %), so automatic mode pairs plain D3Q19 SRT only; fuse = 1 or 2 pairs whatever has an instance.
+//   72 %), as do the 16-bit kernels with extensions (vector issue is what bounds them); the other FP32 sets, D3Q27 and TRT without
+//   extensions gain 9 to 24 points.  Automatic mode goes by PairKernels::pays, measured per instance (collide_pairs.hip);
+//   fuse = 1 or 2 pairs whatever has an instance.
 //   k_collide_pair (fuse = 1): any placement of the workgroups, step t+1 reads from the Infinity Cache, so lag + 4 planes must
 //   fit it with room to spare (512^3 FP32: lag 4 and no cap 79.8 %, lag 3 70 %, lag 5 77 %, lag 8 65 %).
 // mode 1: k_collide_pair (step t+1 reads from the Infinity Cache, any placement of the workgroups); mode 2: k_collide_band (from the L2 of
@@ -747,8 +749,7 @@ static bool pair_plan(const lbmhip_domain* d, PairPlan* plan) {
 	// band by band on each XCD: blocks of ceil(Ny/8) rows, at least 4 rows each
 	plan->block_rows = (d->cfg.Ny+7u)/8u;
 	const bool band_possible = plan->block_rows >= 4u && d->cfg.Nz >= 8u;
-	const bool plain = d->cfg.velocity_set == 19u && d->cfg.collision == LBMHIP_SRT && d->cfg.features == 0u;
-	if (d->fuse < 0 && !(band_possible && plain && (uint64_t)d->cfg.Nx*d->cfg.Ny >= 256ull*256ull)) return false; // automatic mode: where it was measured to pay
+	if (d->fuse < 0 && !(band_possible && plan->k.pays && (uint64_t)d->cfg.Nx*d->cfg.Ny >= 256ull*256ull)) return false; // automatic mode: where it was measured to pay
 	plan->mode = (d->fuse != 1 && band_possible) ? 2 : 1;
 	if (plan->mode == 2) {
 		// tasks per plane of a band, measured with Taylor-Green lattices (tools/fused_sweep.py): 64 for 16-bit DDFs (512^3: 64 rows of one chunk

@@ -121,8 +121,10 @@ int lbmhip_stream_collide_planes(lbmhip_domain* domain, uint64_t t, float fx, fl
  * when no exchange, force-field update or export falls between the steps (lbm.cpp:1354-1459, one stream_collide launch
  * per step there).  A domain that is not split in x or y, without UPDATE_FIELDS, may run them two per launch (same bits as
  * `steps` calls of lbmhip_stream_collide): band by band on each XCD, the second step a few lattice planes behind the first
- * and served by the caches instead of HBM.  Automatic for plain D3Q19 SRT on planes of at least 256 x 256 cells; every
- * other configuration runs one launch per step unless "fuse" asks otherwise.  A paired launch never returns an error of its
+ * and served by the caches instead of HBM.  Automatic on planes of at least 256 x 256 cells for the configurations with a
+ * compiled two-step instance that was measured faster than a launch per step (collide_pairs.hip lists them: D3Q19 and D3Q27
+ * without extensions in every DDF format, FP32 TRT, FP32 with SUBGRID, VOLUME_FORCE, EQUILIBRIUM_BOUNDARIES and their usual
+ * combinations); every other configuration runs one launch per step unless "fuse" asks otherwise.  A paired launch never returns an error of its
  * own: should its assumptions about workgroup placement not hold, the launch that follows it finishes the work step by
  * step and the domain stops pairing (one line on stderr; lbmhip_get_tuning "band_given_up").  Tuning keys: lbmhip_set_tuning. */
 int lbmhip_stream_collide_steps(lbmhip_domain* domain, uint64_t t, uint32_t steps, float fx, float fy, float fz);
@@ -218,8 +220,8 @@ int lbmhip_timer_stop(lbmhip_domain* domain, float* milliseconds); /* waits for 
  * stream_collide launches of a lattice of at least 2^21 cells each try one launch geometry between two events (three
  * times each) and the one with the best median is kept; every geometry computes the same bits.  0 = fixed defaults; the environment variable
  * LBMHIP_AUTOTUNE=0 has the same effect for every domain created afterwards).
- * Two steps per launch (lbmhip_stream_collide_steps, lbmhip_stream_collide_pair_planes): "fuse" (-1 = automatic: plain D3Q19
- * SRT on planes of at least 256 x 256 cells, band by band; 0 = never; 1 = the form whose second step reads through the
+ * Two steps per launch (lbmhip_stream_collide_steps, lbmhip_stream_collide_pair_planes): "fuse" (-1 = automatic: the
+ * configurations measured to gain, on planes of at least 256 x 256 cells, band by band; 0 = never; 1 = the form whose second step reads through the
  * Infinity Cache from any XCD, whenever a compiled instance exists; 2 = band by band on each XCD, whenever a compiled
  * instance exists; LBMHIP_FUSE=0|1|2 sets it for every domain created afterwards).  Band by band: "band_rows" (0 = automatic,
  * 2..4096 lattice rows per band), "band_lag" (0 = automatic, 2..64: planes the second step trails the first by),

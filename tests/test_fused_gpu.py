@@ -168,6 +168,30 @@ def test_automatic_pairing_equals_the_oracle(gpu, storage):
         a.close()
 
 
+@pytest.mark.parametrize("kw,setup,pairs", [
+    (dict(N=(256, 256, 12), nu=0.01, Q=27), setups.taylor_green, True),
+    (dict(N=(256, 256, 12), nu=0.01, collision="TRT"), setups.taylor_green, True),
+    (dict(N=(256, 256, 12), nu=0.01, features=("EQUILIBRIUM_BOUNDARIES", "SUBGRID")), setups.inflow_box, True),
+    (dict(N=(256, 256, 12), nu=0.01, features=("VOLUME_FORCE", "SUBGRID"), f=(2e-4, 1e-5, 0.0)), setups.channel, True),
+    (dict(N=(320, 264, 12), nu=0.01, Q=27, storage="FP16C"), setups.taylor_green, True),
+    (dict(N=(256, 256, 12), nu=0.01, features=("VOLUME_FORCE", "SUBGRID"), f=(2e-4, 0.0, 0.0), collision="TRT"), setups.channel, False),   # has an instance, measured slower
+    (dict(N=(256, 256, 12), nu=0.01, features=("FORCE_FIELD",)), setups.taylor_green, False)])                                        # has none
+def test_automatic_pairing_by_feature_set(gpu, kw, setup, pairs):
+    """Automatic mode goes by what was measured per compiled instance: the sets that gain pair (and give the oracle's bits), the others
+    keep a launch per step."""
+    a = cfd_amd.LBM(**kw); b = H.OracleLBM(**kw)
+    try:
+        a.set_tuning("autotune", 0)
+        setup(a); setup(b)
+        a.run(6); b.run(6, threads=16)
+        assert fused_flag(a) == (2 if pairs else 0) and tuning(a, "fuse") == -1 and tuning(a, "band_given_up") == 0
+        assert np.array_equal(bits(a.domains[0].download_fi()), bits(b.domains[0].fi)), "DDFs differ from the oracle"
+        a.read_from_device(); b.read_from_device()
+        assert np.array_equal(bits(a.rho), bits(b.rho)) and np.array_equal(bits(a.u), bits(b.u))
+    finally:
+        a.close()
+
+
 @pytest.mark.parametrize("kw,setup", [(CHANNEL, setups.channel), (HALF_S, setups.taylor_green), (HALF_C, setups.taylor_green)])
 def test_paired_steps_equal_the_oracle(gpu, kw, setup):
     a = cfd_amd.LBM(**kw); b = H.OracleLBM(**kw)

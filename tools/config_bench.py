@@ -23,6 +23,16 @@ CONFIGS = {
     "tgv512_fp16s": dict(N=(512, 512, 512), Q=19, st="FP16S", coll="SRT", feat=0),
     "tgv512_fp16c": dict(N=(512, 512, 512), Q=19, st="FP16C", coll="SRT", feat=0),
     "q27_384_fp16c": dict(N=(384, 384, 384), Q=27, st="FP16C", coll="SRT", feat=0),
+    "aero512_fp32": dict(N=(512, 512, 512), Q=19, st="FP32", coll="SRT", feat=F["EQUILIBRIUM_BOUNDARIES"] | F["SUBGRID"], mask=True),
+    "aero512_fp16s": dict(N=(512, 512, 512), Q=19, st="FP16S", coll="SRT", feat=F["EQUILIBRIUM_BOUNDARIES"] | F["SUBGRID"], mask=True),
+    "vf512_fp32": dict(N=(512, 512, 512), Q=19, st="FP32", coll="SRT", feat=F["VOLUME_FORCE"], mask=True, f=(2e-4, 0.0, 0.0)),
+    "vf_sgs512_fp32": dict(N=(512, 512, 512), Q=19, st="FP32", coll="SRT", feat=F["VOLUME_FORCE"] | F["SUBGRID"], mask=True, f=(2e-4, 0.0, 0.0)),
+    "eq512_fp32": dict(N=(512, 512, 512), Q=19, st="FP32", coll="SRT", feat=F["EQUILIBRIUM_BOUNDARIES"], mask=True),
+    "mb_eq_sgs512_fp32": dict(N=(512, 512, 512), Q=19, st="FP32", coll="SRT", feat=F["MOVING_BOUNDARIES"] | F["EQUILIBRIUM_BOUNDARIES"] | F["SUBGRID"], mask=True),
+    "q27_384_fp32": dict(N=(384, 384, 384), Q=27, st="FP32", coll="SRT", feat=0),
+    "q27_384_fp16s": dict(N=(384, 384, 384), Q=27, st="FP16S", coll="SRT", feat=0),
+    "q27_512_fp32": dict(N=(512, 512, 512), Q=27, st="FP32", coll="SRT", feat=0),
+    "q27_512_fp16s": dict(N=(512, 512, 512), Q=27, st="FP16S", coll="SRT", feat=0),
     "tgv512_fp32_trt": dict(N=(512, 512, 512), Q=19, st="FP32", coll="TRT", feat=0),
     "tgv512_fp32_sgs": dict(N=(512, 512, 512), Q=19, st="FP32", coll="SRT", feat=F["SUBGRID"]),
     "gui512_fp16s": dict(N=(512, 512, 512), Q=19, st="FP16S", coll="SRT", feat=F["UPDATE_FIELDS"] | F["VOLUME_FORCE"] | F["EQUILIBRIUM_BOUNDARIES"] | F["SUBGRID"], mask=True, f=(0.0, 0.0, 1e-5)),
