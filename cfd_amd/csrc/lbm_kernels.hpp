@@ -657,11 +657,14 @@ struct BandArgs {
 #define LBM_BAND_EXP 0 // diagnostic builds (tools/band_variants.sh): 1 no waits, 2 plain loads in the later steps, 4 write-through stores in step t, 32 wait statistics - 1 gives wrong lattices
 #endif
 __device__ __forceinline__ uint32_t xcd_of_this_wave() { uint32_t x; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(x)); return x&7u; }
+#ifndef LBM_BAND_BLOCKS
+#define LBM_BAND_BLOCKS 1 // the same for the other instances (diagnostic builds)
+#endif
 #ifndef LBM_BAND_P2_BLOCKS
 #define LBM_BAND_P2_BLOCKS 3 // workgroups per CU the register allocation of the two-cells-together instances aims at (diagnostic builds: 5 = 88 registers, 6 spills)
 #endif
 template <int Q, int ST, int COLL, int FEAT, int V = 1, int P = 1>
-__global__ __launch_bounds__(256, (P == 2 && V == 2 ? LBM_BAND_P2_BLOCKS : 1)) void k_collide_band(const Args a, const BandArgs p) {
+__global__ __launch_bounds__(256, (P == 2 && V == 2 ? LBM_BAND_P2_BLOCKS : LBM_BAND_BLOCKS)) void k_collide_band(const Args a, const BandArgs p) {
 	__shared__ uint32_t give_up;
 	const uint32_t Nz = a.Nz, block_of = blockIdx.x&7u, within = blockIdx.x>>3, band = blockIdx.z; // grid = (8*R*xchunks, plane times * steps, bands)
 	const uint32_t bs = block_of*p.block_rows, be = min(bs+p.block_rows, a.Ny); // this block's rows
