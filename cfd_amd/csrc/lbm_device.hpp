@@ -264,6 +264,23 @@ template <> struct Store<ST_FP16C> {
 	static __device__ __forceinline__ raw encode(float x) { rtz_scale_block<1>(&x); return encode_scaled(x); }
 	template <int N> static __device__ __forceinline__ void prescale(float* f) { rtz_scale<N>(f); }
 	template <int N> static __device__ __forceinline__ void prescale(float2v* f) { rtz_scale<N>(f); }
+	// One of the two codes of a dword (h = 0: low half, 1: high half) without taking the dword apart.  decode_half: the low
+	// half arrives sign-extended and shifted in one instruction (sub-dword operand select); encode_half (value already scaled
+	// by 2^-112 towards zero): m holds the code in its bits 27..12 - exponent and mantissa where they are, the sign moved from
+	// bit 31 to bit 27 - and one shift with a sub-dword destination writes it into its half of w, keeping the other half.
+	static __device__ __forceinline__ float decode_half(uint32_t w, int h) {
+		uint32_t t;
+		if (h == 0) asm("v_lshlrev_b32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(t) : "s"(12u), "v"(w));
+		else t = (uint32_t)((int32_t)w>>4);
+		return __uint_as_float(t&0x87FFF000u)*0x1p112f;
+	}
+	static __device__ __forceinline__ void encode_half(uint32_t& w, int h, float scaled) {
+		const uint32_t u = __float_as_uint(scaled)+0x00000800u;
+		uint32_t m; // (u & mask) | (u>>4 & ~mask) in one instruction
+		asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(m) : "s"(0x07FFF000u), "v"(u), "v"(u>>4));
+		if (h == 0) asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(w) : "s"(12u), "v"(m));
+		else asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(w) : "s"(12u), "v"(m));
+	}
 	typedef uint32_t raw2;
 	static __device__ __forceinline__ float2v decode2(raw2 r) {
 		float2v v;

@@ -292,7 +292,7 @@ __device__ __forceinline__ void collide_row_wide(const Args& a, const uint32_t c
 				const uint32_t xv = x+(uint32_t)v;
 				const uint8_t bo = fl[v]&TYPE_BO;
 				float f[Q];
-				constexpr bool halves = ST == ST_FP16S; // the two DDFs of a dword are decoded from it and encoded into it in place
+				constexpr bool halves = sizeof(raw) == 2; // the two 16-bit DDFs of a dword are decoded from it and encoded into it in place
 				if constexpr (halves) static_for<0, Q, 1>([&](auto I) { f[I] = S::decode_half(pair_of<uint32_t, V>(d[I], v&~1), v&1); });
 				else static_for<0, Q, 1>([&](auto I) { f[I] = S::decode(d[I][v]); });
 				if (feat(F_MOVING_BOUNDARIES) && bo == TYPE_MS) apply_moving_boundaries<Q>(f, a, xv, yq, zq);

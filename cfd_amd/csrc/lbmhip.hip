@@ -638,12 +638,14 @@ template <int ST> __global__ __launch_bounds__(256) void k_convert_ddfs(const vo
 		}
 	} else { // two neighbouring values at a time, the packed forms used when a lane collides two cells together; count is even
 		typedef typename S::raw2 raw2;
-		if constexpr (ST == ST_FP16S) if (pairs == 2) { // each half of a dword on its own, converted in place (one cell after the other with two cells per lane)
+		if constexpr (ST != ST_FP32) if (pairs == 2) { // each half of a dword on its own, converted in place (one cell after the other with two cells per lane)
 			for (uint64_t i = first; 2u*i < count; i += stride) {
 				if (to_storage) {
 					const float2v x = static_cast<const float2v*>(in)[i];
+					float v[2] = {x.x, x.y};
+					S::template prescale<2>(v);
 					uint32_t w = 0xDEADBEEFu; // whichever half is written first has to survive the writing of the other
-					if (i&1u) { S::encode_half(w, 0, x.x); S::encode_half(w, 1, x.y); } else { S::encode_half(w, 1, x.y); S::encode_half(w, 0, x.x); }
+					if (i&1u) { S::encode_half(w, 0, v[0]); S::encode_half(w, 1, v[1]); } else { S::encode_half(w, 1, v[1]); S::encode_half(w, 0, v[0]); }
 					static_cast<uint32_t*>(out)[i] = w;
 				} else {
 					const uint32_t w = static_cast<const uint32_t*>(in)[i];

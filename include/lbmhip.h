@@ -204,7 +204,7 @@ int lbmhip_object_sum(lbmhip_domain* domain, int what, uint8_t flag_marker, cons
  * applied to a HOST array on `device`, with the same device code the lattice kernels use.  to_storage != 0: in = count
  * floats, out = count stored values (float for FP32, 16-bit otherwise); to_storage == 0: the reverse.  pairs != 0 converts
  * two neighbouring values at a time with the packed instructions the kernels use when a lane collides two cells together
- * (count must be even), pairs == 2 (FP16S) each half of a dword in place as the kernels do when a lane collides its two cells
+ * (count must be even), pairs == 2 (16-bit formats) each half of a dword in place as the kernels do when a lane collides its two cells
  * one after the other; the results are the same.  For hosts that prepare or inspect raw DDFs, and for checking the
  * conversions exhaustively.  Complete when the call returns. */
 int lbmhip_convert_ddfs(int device, uint32_t storage, int to_storage, int pairs, const void* in, void* out, uint64_t count);

@@ -48,7 +48,7 @@ def fp16c_encode_reference(bits):
 def test_fp16c_decode_all_codes(gpu):
     codes = np.arange(65536, dtype=np.uint16)
     want = np.array([oracle.oracle_fp16c_to_float(int(c)) for c in codes], dtype=np.float32)
-    for pairs in (0, 1):
+    for pairs in (0, 1, 2):
         got = convert("FP16C", 0, pairs, codes, np.float32)
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "pairs=%d" % pairs
 
@@ -73,7 +73,7 @@ def test_fp16s_both_directions(gpu):
 def check_encode(bits):
     want = fp16c_encode_reference(bits)
     finite = (bits & 0x7F800000) != 0x7F800000  # the payload of a NaN is not preserved; DDFs are finite
-    for pairs in (0, 1):
+    for pairs in (0, 1, 2):
         got = convert("FP16C", 1, pairs, bits.view(np.float32), np.uint16)
         bad = np.flatnonzero((got != want) & finite)
         assert bad.size == 0, "pairs=%d: %d mismatches, first at bits 0x%08x: got 0x%04x, want 0x%04x" % (pairs, bad.size, bits[bad[0]], got[bad[0]], want[bad[0]])
