@@ -64,6 +64,7 @@ struct lbmhip_domain {
 	uint32_t band_launches; // number of the last k_collide_band launch (the stamp its workgroups leave)
 	int band_unchecked, band_given_up;            // launches since the error word was last read; launches found to have given up waits (their tasks were redone)
 	int compute_units;
+	int xcd_round_robin; // workgroups i and i+8 of a launch share an XCD (probed once per device)
 };
 
 // 64-bit safe fill (fields of the largest lattices exceed what 32-bit element counts can address)
@@ -207,6 +208,38 @@ uint32_t lbmhip_bandwidth_bytes_per_cell(uint32_t Q, uint32_t storage, uint32_t 
 	return b;
 }
 
+// Which XCD the workgroups of a launch land on.  k_collide_band lets blockIdx.x % 8 stand for "the same XCD" (workgroups are
+// dealt to the XCDs round-robin by their linear index; its grids are multiples of 8 wide).  The launch itself checks every
+// hand-over against the XCD number it reads from the hardware, so a false assumption only costs time; this probe, once per
+// device, finds it out before the first such launch: 16 x 4 workgroups record where they ran, and every workgroup has to
+// sit where the first workgroup with the same blockIdx.x % 8 sits.
+__global__ __launch_bounds__(64) void k_probe_xcd(uint32_t* where) {
+	if (threadIdx.x == 0u) where[blockIdx.y*gridDim.x+blockIdx.x] = xcd_of_this_wave();
+}
+static int xcd_round_robin(int device) { // 1: as assumed, 0: not (or the probe failed); the device is current
+	static std::mutex lock;
+	static std::map<int, int> known;
+	std::lock_guard<std::mutex> guard(lock);
+	const auto it = known.find(device);
+	if (it != known.end()) return it->second;
+	int result = 0;
+	uint32_t* where = nullptr;
+	uint32_t host[64];
+	if (hipMalloc((void**)&where, sizeof(host)) == hipSuccess) {
+		hipLaunchKernelGGL(k_probe_xcd, dim3(16, 4), dim3(64), 0, nullptr, where);
+		if (hipGetLastError() == hipSuccess && hipMemcpy(host, where, sizeof(host), hipMemcpyDeviceToHost) == hipSuccess) {
+			result = 1;
+			for (int k = 0; k < 64; k++) if (host[k] != host[k%8]) result = 0;
+		}
+		(void)hipFree(where);
+	}
+	(void)hipGetLastError();
+	if (!result) fprintf(stderr, "lbmhip: device %d does not place workgroups on its XCDs round-robin; two steps per launch use the form that does not depend on it\n", device);
+	known[device] = result;
+	return result;
+}
+
+
 int lbmhip_domain_create(const lbmhip_config* c, lbmhip_domain** out) {
 	NEED(c && out, "lbmhip_domain_create: null argument");
 	*out = nullptr;
@@ -285,6 +318,7 @@ int lbmhip_domain_create(const lbmhip_config* c, lbmhip_domain** out) {
 	d->band_rows = 0; d->band_lag = 0; d->band_blocks_per_cu = -1; d->band_spin_limit = -1; d->band_steps = 0; d->band_used_steps = 0;
 	{ const char* env = getenv("LBMHIP_FUSE"); if (env && env[0] >= '0' && env[0] <= '2' && !env[1]) d->fuse = env[0]-'0'; }
 	if (e == hipSuccess) e = hipDeviceGetAttribute(&d->compute_units, hipDeviceAttributeMultiprocessorCount, c->device);
+	d->xcd_round_robin = e == hipSuccess && c->Dx == 1u && c->Dy == 1u && c->Nz >= 8u ? xcd_round_robin(c->device) : 0;
 	if (e == hipSuccess && c->Dx == 1u && c->Dy == 1u && c->Nz >= 8u) { // what k_collide_pair needs, whether or not it is ever used (264 KB at 512 planes)
 		d->pair_replica_stride = (c->Nz+63u)/64u*64u+32u; // the replicas start on different cache lines, an odd number of lines apart
 		d->pair_sync_words = (uint64_t)PAIR_REPLICAS*d->pair_replica_stride+(uint64_t)c->Nz*PAIR_SHARDS*PAIR_SHARD_STRIDE;
@@ -484,6 +518,7 @@ int lbmhip_get_tuning(lbmhip_domain* d, const char* key, int* value) {
 	if (!strcmp(key, "pair_lag")) { *value = d->pair_used ? d->pair_used_lag : d->pair_lag; return 0; }
 	if (!strcmp(key, "pair_cells_together")) { *value = d->pair_cells_together; return 0; }
 	if (!strcmp(key, "pair_block")) { *value = d->pair_block; return 0; }
+	if (!strcmp(key, "xcd_round_robin")) { *value = d->xcd_round_robin; return 0; } // what the placement probe found (0 also for domains that never pair)
 	if (!strcmp(key, "pairs_steps")) { *value = pairs_steps(d); return 0; } // would two steps of this domain share a launch (whole lattice, or the inner planes of a z-slab)?
 	if (!strcmp(key, "pair_blocks_per_cu")) { *value = d->pair_used ? d->pair_used_blocks_per_cu : d->pair_blocks_per_cu; return 0; }
 	return fail("unknown tuning key '%s'", key);
@@ -750,7 +785,7 @@ static bool pair_plan(const lbmhip_domain* d, PairPlan* plan) {
 	const int per_cu_max = 8*256/(int)plan->block;
 	// band by band on each XCD: blocks of ceil(Ny/8) rows, at least 4 rows each
 	plan->block_rows = (d->cfg.Ny+7u)/8u;
-	const bool band_possible = plan->block_rows >= 4u && d->cfg.Nz >= 8u;
+	const bool band_possible = plan->block_rows >= 4u && d->cfg.Nz >= 8u && d->xcd_round_robin;
 	if (d->fuse < 0 && !(band_possible && plan->k.pays && (uint64_t)d->cfg.Nx*d->cfg.Ny >= 256ull*256ull)) return false; // automatic mode: where it was measured to pay
 	plan->mode = (d->fuse != 1 && band_possible) ? 2 : 1;
 	if (plan->mode == 2) {

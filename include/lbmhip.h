@@ -232,7 +232,9 @@ int lbmhip_timer_stop(lbmhip_domain* domain, float* milliseconds); /* waits for 
  * Read-only keys of lbmhip_get_tuning: "tuned" (the search has finished), "jit" (the last launch ran a kernel
  * compiled at run time), "pairs_steps" (two steps of this domain would share a launch), "fused" (what the last
  * lbmhip_stream_collide_steps / lbmhip_stream_collide_pair_planes call did: 0 = a launch per step, 1 or 2 = the form it
- * paired its steps in), "band_given_up" (paired launches found to have given up waits; their work was redone). */
+ * paired its steps in), "band_given_up" (paired launches found to have given up waits; their work was redone), "xcd_round_robin" (1 when
+ * the probe at domain creation found workgroups i and i+8 of a launch on the same XCD, which the band-by-band form builds on; 0
+ * sends "fuse" -1 and 2 to form 1). */
 int lbmhip_set_tuning(lbmhip_domain* domain, const char* key, int value);
 /* Reads back a launch setting ("cells_per_thread", "cells_together", "blocks_per_cu", "block", "autotune"), "tuned" (1 once
  * the geometry search has finished; the launch settings then report its choice) or "jit" (1 when the last stream_collide

@@ -161,6 +161,7 @@ def test_automatic_pairing_equals_the_oracle(gpu, storage):
         setups.taylor_green(a); setups.taylor_green(b)
         a.run(6); b.run(6, threads=16)
         assert fused_flag(a) == 2 and tuning(a, "fuse") == -1 and tuning(a, "band_given_up") == 0
+        assert tuning(a, "xcd_round_robin") == 1  # the placement probe at domain creation agrees with what the launches found
         assert np.array_equal(bits(a.domains[0].download_fi()), bits(b.domains[0].fi)), "DDFs differ from the oracle"
         a.read_from_device(); b.read_from_device()
         assert np.array_equal(bits(a.rho), bits(b.rho)) and np.array_equal(bits(a.u), bits(b.u))
