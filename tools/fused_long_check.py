@@ -24,7 +24,7 @@ for fuse in (-1, 0):
     fi = lbm.domains[0].download_fi()
     n = 512 ** 3
     crcs[fuse] = [zlib.crc32(fi[i * n:(i + 1) * n].tobytes()) for i in range(19)]
-    print("fuse %2d: paired launches %d, CRC of stream 0 %08x, of stream 18 %08x" % (fuse, v.value, crcs[fuse][0], crcs[fuse][18]), flush=True)
+    print("fuse %2d: form of the paired launches %d, launches that gave up waits %d, CRC of stream 0 %08x, of stream 18 %08x" % (fuse, v.value, lbm.get_tuning("band_given_up"), crcs[fuse][0], crcs[fuse][18]), flush=True)
     lbm.close()
 print("%s, %d steps: %s" % (storage, steps, "bit-identical" if crcs[-1] == crcs[0] else "DIFFERENT"))
 sys.exit(0 if crcs[-1] == crcs[0] else 1)
