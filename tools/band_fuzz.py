@@ -1,5 +1,6 @@
 """Diagnostic: random lattices, feature sets and launch geometries through lbmhip_stream_collide_steps with two to four steps per
-launch (fuse = 2, or 1 for the form without bands), compared bit for bit with one launch per step.  (GPU needed)
+launch (fuse = 2, or 1 for the form without bands; one domain, or two or three slabs in one process), compared bit for bit with
+one launch per step.  (GPU needed)
 usage: python tools/band_fuzz.py [cases] [seed]"""
 import os
 import sys
@@ -28,7 +29,10 @@ for case in range(cases):
     Nx = int(rng.choice([rng.randint(2, 40), rng.randint(40, 300), rng.randint(300, 700), 64, 128, 256, 512]))
     if half:
         Nx += Nx % 2
-    N = (max(Nx, 2), int(rng.randint(25, 96)), int(rng.randint(8, 40)))
+    Dz = int(rng.choice([1, 1, 1, 2, 3]))  # slabs in one process: lbmhip_stream_collide_pair_planes between the exchanges
+    N = (max(Nx, 2), int(rng.randint(25, 96)), int(rng.randint(8, 40)) if Dz == 1 else int(rng.randint(10, 30))*Dz)
+    if Dz > 1:
+        kw["D"] = (1, 1, Dz)
     feats = kw.get("features", ())
     setup = setups.inflow_box if "EQUILIBRIUM_BOUNDARIES" in feats else setups.channel if "VOLUME_FORCE" in feats else setups.taylor_green
     fuse = 1 if rng.rand() < 0.15 else 2
@@ -43,8 +47,7 @@ for case in range(cases):
             a.set_tuning(k, v)
         setup(a); setup(b)
         a.run(steps); b.run(steps)
-        fa = a.domains[0].download_fi(); fb = b.domains[0].download_fi()
-        same = bool(np.array_equal(fa.view(np.uint8), fb.view(np.uint8)))
+        same = all(bool(np.array_equal(da.download_fi().view(np.uint8), db.download_fi().view(np.uint8))) for da, db in zip(a.domains, b.domains))
         form, gave = a.get_tuning("fused"), a.get_tuning("band_given_up")
         if not same or gave:
             bad += 1
