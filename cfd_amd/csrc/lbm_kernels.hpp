@@ -654,7 +654,7 @@ struct BandArgs {
 	uint32_t first[4], count[4]; // planes of step t+s: first[s] .. first[s]+count[s]-1 modulo Nz, first[s] >= first[s-1]+1 (not reduced modulo Nz)
 };
 #ifndef LBM_BAND_EXP
-#define LBM_BAND_EXP 0 // diagnostic builds (tools/band_variants.sh): 1 no waits, 2 plain loads in the later steps, 4 write-through stores in step t, 32 wait statistics - 1 gives wrong lattices
+#define LBM_BAND_EXP 0 // diagnostic builds (tools/band_variants.sh): 1 no waits, 2 plain loads in the later steps, 4 write-through stores in step t, 8 no drain and no stamp after a step, 32 wait statistics - 1 and 8 give wrong lattices
 #endif
 __device__ __forceinline__ uint32_t xcd_of_this_wave() { uint32_t x; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(x)); return x&7u; }
 #ifndef LBM_BAND_BLOCKS
@@ -744,7 +744,7 @@ __global__ __launch_bounds__(256, (P == 2 && V == 2 ? LBM_BAND_P2_BLOCKS : LBM_B
 			collide_row_wide<Q, ST, COLL, FEAT, V, P, false, MEM2>(b, chunk, y, z);
 		}
 	}
-	if (s+1u < p.steps) {
+	if (s+1u < p.steps && !(LBM_BAND_EXP&8)) {
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's stores have been acknowledged by the L2
 		__syncthreads();
 		if (threadIdx.x == 0u) *(volatile uint32_t*)(p.stamps+s*p.stamps_per_step+((((uint64_t)block_of*p.bands+band)*Nz+z)*p.R+row)*a.xchunks+chunk) = p.stamp|xcd;
