@@ -8,7 +8,8 @@ SWEEP_CAPS / SWEEP_LAGS empty: skip the sweep of k_collide_pair; SWEEP_BAND_ROWS
 import ctypes as C
 import sys
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import cfd_amd
 from cfd_amd import lbm as L
 from cfd_amd import setups
