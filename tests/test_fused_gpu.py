@@ -309,3 +309,16 @@ def test_headline_lattice_paired_equals_single_launches(gpu, storage):
             n = 512 ** 3
             crcs[fuse] = [zlib.crc32(fi[i * n:(i + 1) * n]) for i in range(19)]
     assert crcs[-1] == crcs[0]
+
+
+def test_random_lattices_feature_sets_and_geometries(gpu):
+    """tools/band_fuzz.py: 60 random combinations of lattice, feature set, form, band height, lag, steps per launch, workgroup size
+    and slabs, every one bit-identical to a launch per step."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "band_fuzz.py"), "60", "5"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "60 cases, 0 bad" in r.stdout
+
