@@ -176,7 +176,8 @@ def test_automatic_pairing_equals_the_oracle(gpu, storage):
     (dict(N=(256, 256, 12), nu=0.01, features=("VOLUME_FORCE", "SUBGRID"), f=(2e-4, 1e-5, 0.0)), setups.channel, True),
     (dict(N=(320, 264, 12), nu=0.01, Q=27, storage="FP16C"), setups.taylor_green, True),
     (dict(N=(256, 256, 12), nu=0.01, features=("VOLUME_FORCE", "SUBGRID"), f=(2e-4, 0.0, 0.0), collision="TRT"), setups.channel, False),   # has an instance, measured slower
-    (dict(N=(256, 256, 12), nu=0.01, features=("FORCE_FIELD",)), setups.taylor_green, False)])                                        # has none
+    (dict(N=(256, 256, 12), nu=0.01, features=("FORCE_FIELD", "EQUILIBRIUM_BOUNDARIES")), setups.sphere_force, True),
+    (dict(N=(256, 256, 12), nu=0.01, features=("MOVING_BOUNDARIES",)), setups.taylor_green, False)])                                  # has none
 def test_automatic_pairing_by_feature_set(gpu, kw, setup, pairs):
     """Automatic mode goes by what was measured per compiled instance: the sets that gain pair (and give the oracle's bits), the others
     keep a launch per step."""

@@ -17,7 +17,8 @@ SETS = [  # what collide_pairs.hip holds
     dict(Q=27, storage="FP16S"), dict(Q=27, storage="FP16C"),
     dict(Q=19, storage="FP32", features=("SUBGRID",)), dict(Q=19, storage="FP32", features=("VOLUME_FORCE",), f=(1e-4, 2e-5, -3e-5)),
     dict(Q=19, storage="FP32", features=("VOLUME_FORCE", "SUBGRID"), f=(1e-4, 0.0, 0.0)), dict(Q=19, storage="FP32", features=("EQUILIBRIUM_BOUNDARIES",)),
-    dict(Q=19, storage="FP32", features=("EQUILIBRIUM_BOUNDARIES", "SUBGRID")),
+    dict(Q=19, storage="FP32", features=("EQUILIBRIUM_BOUNDARIES", "SUBGRID")), dict(Q=19, storage="FP32", features=("FORCE_FIELD",)),
+    dict(Q=19, storage="FP32", features=("FORCE_FIELD", "EQUILIBRIUM_BOUNDARIES")),
     dict(Q=19, storage="FP32", collision="TRT", features=("VOLUME_FORCE", "SUBGRID"), f=(1e-4, 0.0, 0.0)),
     dict(Q=19, storage="FP16S", collision="TRT", features=("VOLUME_FORCE", "SUBGRID"), f=(1e-4, 0.0, 0.0)),
     dict(Q=27, storage="FP16C", features=("FORCE_FIELD", "VOLUME_FORCE"), f=(1e-5, 0.0, 0.0)),
@@ -46,6 +47,9 @@ for case in range(cases):
         for k, v in tune.items():
             a.set_tuning(k, v)
         setup(a); setup(b)
+        if "FORCE_FIELD" in feats:  # a force on every cell (the kernels read it for fluid cells)
+            F = np.random.RandomState(case).uniform(-1e-5, 1e-5, a.F.shape).astype(np.float32)
+            a.F[...] = F; b.F[...] = F
         a.run(steps); b.run(steps)
         same = all(bool(np.array_equal(da.download_fi().view(np.uint8), db.download_fi().view(np.uint8))) for da, db in zip(a.domains, b.domains))
         form, gave = a.get_tuning("fused"), a.get_tuning("band_given_up")

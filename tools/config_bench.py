@@ -29,6 +29,9 @@ CONFIGS = {
     "vf_sgs512_fp32": dict(N=(512, 512, 512), Q=19, st="FP32", coll="SRT", feat=F["VOLUME_FORCE"] | F["SUBGRID"], mask=True, f=(2e-4, 0.0, 0.0)),
     "eq512_fp32": dict(N=(512, 512, 512), Q=19, st="FP32", coll="SRT", feat=F["EQUILIBRIUM_BOUNDARIES"], mask=True),
     "mb_eq_sgs512_fp32": dict(N=(512, 512, 512), Q=19, st="FP32", coll="SRT", feat=F["MOVING_BOUNDARIES"] | F["EQUILIBRIUM_BOUNDARIES"] | F["SUBGRID"], mask=True),
+    "mb512_fp32": dict(N=(512, 512, 512), Q=19, st="FP32", coll="SRT", feat=F["MOVING_BOUNDARIES"], mask=True),
+    "ff_eq512_fp32": dict(N=(512, 512, 512), Q=19, st="FP32", coll="SRT", feat=F["FORCE_FIELD"] | F["EQUILIBRIUM_BOUNDARIES"], mask=True),
+    "ff512_fp32": dict(N=(512, 512, 512), Q=19, st="FP32", coll="SRT", feat=F["FORCE_FIELD"], mask=True),
     "q27_384_fp32": dict(N=(384, 384, 384), Q=27, st="FP32", coll="SRT", feat=0),
     "q27_384_fp16s": dict(N=(384, 384, 384), Q=27, st="FP16S", coll="SRT", feat=0),
     "q27_512_fp32": dict(N=(512, 512, 512), Q=27, st="FP32", coll="SRT", feat=0),
