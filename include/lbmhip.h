@@ -123,8 +123,8 @@ int lbmhip_stream_collide_planes(lbmhip_domain* domain, uint64_t t, float fx, fl
  * `steps` calls of lbmhip_stream_collide): band by band on each XCD, the second step a few lattice planes behind the first
  * and served by the caches instead of HBM.  Automatic on planes of at least 256 x 256 cells for the configurations with a
  * compiled two-step instance that was measured faster than a launch per step (collide_pairs.hip lists them: D3Q19 and D3Q27
- * without extensions in every DDF format, FP32 TRT, FP32 with SUBGRID, VOLUME_FORCE, EQUILIBRIUM_BOUNDARIES and their usual
- * combinations); every other configuration runs one launch per step unless "fuse" asks otherwise.  A paired launch never returns an error of its
+ * without extensions in every DDF format, FP32 TRT, FP32 with SUBGRID, VOLUME_FORCE, EQUILIBRIUM_BOUNDARIES, FORCE_FIELD and their
+ * usual combinations); every other configuration runs one launch per step unless "fuse" asks otherwise.  A paired launch never returns an error of its
  * own: should its assumptions about workgroup placement not hold, the launch that follows it finishes the work step by
  * step and the domain stops pairing (one line on stderr; lbmhip_get_tuning "band_given_up").  Tuning keys: lbmhip_set_tuning. */
 int lbmhip_stream_collide_steps(lbmhip_domain* domain, uint64_t t, uint32_t steps, float fx, float fy, float fz);
