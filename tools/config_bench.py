@@ -1,7 +1,7 @@
 """Diagnostic: single-GPU stream_collide rate of the five benchmark configurations (GPU needed).  The lattices start at
 rest (the rate does not depend on the field data); solids are an extruded pillar mask uploaded plane by plane, so no
 host copy of the big lattices is ever made.
-usage: python tools/config_bench.py [--sweep] [--geometry=V,P,blocks_per_cu,block] [--steps=n] [--fuse=-1|1|2] [--band=rows,lag,blocks_per_cu[,lanes per workgroup]] [--together=1|2] [--moving] [names...]
+usage: python tools/config_bench.py [--sweep] [--geometry=V,P,blocks_per_cu,block] [--steps=n] [--fuse=-1|1|2] [--band=rows,lag,blocks_per_cu[,lanes per workgroup]] [--together=1|2] [--moving] [names... | fp32_features_<mask>]
 (--sweep also tries every launch geometry; --geometry fixes it and skips the library's search, for profiler passes that must see one kernel;
 --fuse hands the timed steps to lbmhip_stream_collide_steps in one call with that "fuse" setting: two steps per launch where the library has an
 instance, --band fixes k_collide_band's geometry; --moving starts from a vortex field instead of a lattice at rest)"""
@@ -171,4 +171,7 @@ TOGETHER = next((int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--t
 BAND = next((tuple(int(v) for v in a.split("=")[1].split(",")) for a in sys.argv[1:] if a.startswith("--band=")), None)
 names = [a for a in sys.argv[1:] if not a.startswith("--")]
 for name in (names or list(CONFIGS)):
+    if name not in CONFIGS and name.startswith("fp32_features_"):  # any feature mask: fp32_features_<decimal mask>, D3Q19 SRT FP32 512^3 with the pillar mask
+        m = int(name.rsplit("_", 1)[1])
+        CONFIGS[name] = dict(N=(512, 512, 512), Q=19, st="FP32", coll="SRT", feat=m, mask=True, f=(1e-4, 0.0, 0.0) if m & F["VOLUME_FORCE"] else (0.0, 0.0, 0.0))
     run(name, CONFIGS[name])
