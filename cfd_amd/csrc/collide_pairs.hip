@@ -11,6 +11,10 @@ namespace lbm {
 PairKernels select_collide_pair(int Q, int ST, int COLL, int FEAT, int V, int P) {
 	LBM_PAIR(19, ST_FP32, COLL_SRT, 0, 1, 1, true)                                    // benchmark: no extension; 88 against 68
 	LBM_PAIR(19, ST_FP32, COLL_TRT, 0, 1, 1, true)                                    // 87 against 65
+	LBM_PAIR(19, ST_FP32, COLL_TRT, F_VOLUME_FORCE, 1, 1, true)                       // 78 against 66
+	LBM_PAIR(19, ST_FP32, COLL_TRT, F_SUBGRID, 1, 1, true)                            // 77 against 66
+	LBM_PAIR(19, ST_FP32, COLL_TRT, F_EQUILIBRIUM_BOUNDARIES|F_SUBGRID, 1, 1, true)   // 76 against 66
+	LBM_PAIR(19, ST_FP32, COLL_TRT, F_EQUILIBRIUM_BOUNDARIES, 1, 1, true)             // 87 against 66
 	LBM_PAIR(19, ST_FP32, COLL_TRT, F_VOLUME_FORCE|F_SUBGRID, 1, 1, false)            // force-driven channel; 64 against 69
 	LBM_PAIR(19, ST_FP32, COLL_SRT, F_EQUILIBRIUM_BOUNDARIES|F_SUBGRID, 1, 1, true)   // the reference's aerodynamics setups; 86 against 66
 	LBM_PAIR(19, ST_FP32, COLL_SRT, F_SUBGRID, 1, 1, true)                            // 84 against 66

@@ -23,7 +23,9 @@ SETS = [  # what collide_pairs.hip holds
     dict(Q=19, storage="FP32", features=("FORCE_FIELD", "VOLUME_FORCE"), f=(1e-4, 0.0, 0.0)), dict(Q=19, storage="FP32", features=("FORCE_FIELD", "VOLUME_FORCE", "SUBGRID"), f=(1e-4, 0.0, 0.0)),
     dict(Q=19, storage="FP32", features=("FORCE_FIELD", "EQUILIBRIUM_BOUNDARIES", "SUBGRID")), dict(Q=19, storage="FP32", features=("FORCE_FIELD", "VOLUME_FORCE", "EQUILIBRIUM_BOUNDARIES"), f=(1e-4, 0.0, 0.0)),
     dict(Q=19, storage="FP32", features=("FORCE_FIELD", "VOLUME_FORCE", "EQUILIBRIUM_BOUNDARIES", "SUBGRID"), f=(1e-4, 0.0, 0.0)),
-    dict(Q=19, storage="FP32", collision="TRT", features=("VOLUME_FORCE", "SUBGRID"), f=(1e-4, 0.0, 0.0)),
+    dict(Q=19, storage="FP32", collision="TRT", features=("VOLUME_FORCE", "SUBGRID"), f=(1e-4, 0.0, 0.0)), dict(Q=19, storage="FP32", collision="TRT", features=("VOLUME_FORCE",), f=(1e-4, 0.0, 0.0)),
+    dict(Q=19, storage="FP32", collision="TRT", features=("SUBGRID",)), dict(Q=19, storage="FP32", collision="TRT", features=("EQUILIBRIUM_BOUNDARIES",)),
+    dict(Q=19, storage="FP32", collision="TRT", features=("EQUILIBRIUM_BOUNDARIES", "SUBGRID")),
     dict(Q=19, storage="FP16S", collision="TRT", features=("VOLUME_FORCE", "SUBGRID"), f=(1e-4, 0.0, 0.0)),
     dict(Q=27, storage="FP16C", features=("FORCE_FIELD", "VOLUME_FORCE"), f=(1e-5, 0.0, 0.0)),
 ]
