@@ -7,7 +7,7 @@ namespace lbm {
 // Last column: band by band against a launch per step, 512^3 (D3Q27: 384^3 too), vortex field, in % of 8 TB/s (tools/config_bench.py --fuse=2 --moving).
 // The kernels that fill the vector issue slots already (16-bit DDFs with extensions) or hold few waves (132 registers) lose; instances
 // that lost and have no other use were dropped: FP32 + MOVING_BOUNDARIES (55 against 66), + EQUILIBRIUM_BOUNDARIES + SUBGRID (54 against 68),
-// FP16S + EQUILIBRIUM_BOUNDARIES + SUBGRID (58 against 65).
+// FP16S + EQUILIBRIUM_BOUNDARIES + SUBGRID (58 against 65), FP16S + SUBGRID (62 against 66).
 PairKernels select_collide_pair(int Q, int ST, int COLL, int FEAT, int V, int P) {
 	LBM_PAIR(19, ST_FP32, COLL_SRT, 0, 1, 1, true)                                    // benchmark: no extension; 88 against 68
 	LBM_PAIR(19, ST_FP32, COLL_TRT, 0, 1, 1, true)                                    // 87 against 65
@@ -34,6 +34,8 @@ PairKernels select_collide_pair(int Q, int ST, int COLL, int FEAT, int V, int P)
 	LBM_PAIR(27, ST_FP32, COLL_SRT, 0, 1, 1, true)                                    // 86 against 66
 	LBM_PAIR(19, ST_FP16S, COLL_SRT, 0, 2, 1, true)                                   // 16-bit DDFs: two cells per lane (dword accesses); 79 against 65
 	LBM_PAIR(19, ST_FP16S, COLL_SRT, 0, 2, 2, true)
+	LBM_PAIR(19, ST_FP16S, COLL_SRT, F_EQUILIBRIUM_BOUNDARIES, 2, 1, true)            // 74 against 66
+	LBM_PAIR(19, ST_FP16S, COLL_SRT, F_VOLUME_FORCE, 2, 1, true)                      // 67 against 65
 	LBM_PAIR(19, ST_FP16C, COLL_SRT, 0, 2, 1, true)                                   // 71 against 65
 	LBM_PAIR(19, ST_FP16S, COLL_TRT, F_VOLUME_FORCE|F_SUBGRID, 2, 1, false)           // force-driven channel, 16-bit DDFs; 44-49 against 57
 	LBM_PAIR(19, ST_FP16S, COLL_TRT, F_VOLUME_FORCE|F_SUBGRID, 2, 2, false)

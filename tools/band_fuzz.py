@@ -14,7 +14,7 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 SETS = [  # what collide_pairs.hip holds
     dict(Q=19, storage="FP32"), dict(Q=19, storage="FP32", collision="TRT"), dict(Q=27, storage="FP32"), dict(Q=19, storage="FP16S"), dict(Q=19, storage="FP16C"),
-    dict(Q=27, storage="FP16S"), dict(Q=27, storage="FP16C"),
+    dict(Q=27, storage="FP16S"), dict(Q=27, storage="FP16C"), dict(Q=19, storage="FP16S", features=("EQUILIBRIUM_BOUNDARIES",)), dict(Q=19, storage="FP16S", features=("VOLUME_FORCE",), f=(1e-4, 0.0, 0.0)),
     dict(Q=19, storage="FP32", features=("SUBGRID",)), dict(Q=19, storage="FP32", features=("VOLUME_FORCE",), f=(1e-4, 2e-5, -3e-5)),
     dict(Q=19, storage="FP32", features=("VOLUME_FORCE", "SUBGRID"), f=(1e-4, 0.0, 0.0)), dict(Q=19, storage="FP32", features=("EQUILIBRIUM_BOUNDARIES",)),
     dict(Q=19, storage="FP32", features=("EQUILIBRIUM_BOUNDARIES", "SUBGRID")), dict(Q=19, storage="FP32", features=("FORCE_FIELD",)),

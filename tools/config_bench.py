@@ -174,6 +174,9 @@ for name in (names or list(CONFIGS)):
     if name not in CONFIGS and name.startswith("fp32_trt_features_"):
         m = int(name.rsplit("_", 1)[1])
         CONFIGS[name] = dict(N=(512, 512, 512), Q=19, st="FP32", coll="TRT", feat=m, mask=True, f=(1e-4, 0.0, 0.0) if m & F["VOLUME_FORCE"] else (0.0, 0.0, 0.0))
+    if name not in CONFIGS and name.startswith("fp16s_features_"):
+        m = int(name.rsplit("_", 1)[1])
+        CONFIGS[name] = dict(N=(512, 512, 512), Q=19, st="FP16S", coll="SRT", feat=m, mask=True, f=(1e-4, 0.0, 0.0) if m & F["VOLUME_FORCE"] else (0.0, 0.0, 0.0))
     if name not in CONFIGS and name.startswith("fp32_features_"):  # any feature mask: fp32_features_<decimal mask>, D3Q19 SRT FP32 512^3 with the pillar mask
         m = int(name.rsplit("_", 1)[1])
         CONFIGS[name] = dict(N=(512, 512, 512), Q=19, st="FP32", coll="SRT", feat=m, mask=True, f=(1e-4, 0.0, 0.0) if m & F["VOLUME_FORCE"] else (0.0, 0.0, 0.0))
